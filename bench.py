@@ -1,0 +1,181 @@
+"""Headline benchmark: device-resident decode of a synthetic 1B-row int64 ORC column.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the RLE v2 decode path (header scan, segment prefix sums, run-table
+emission, value expansion) over one stripe set of `--rows` values that is already resident in
+HBM, through the C ABI of liborcd.so.  Stripes are independent, so with N GPUs every rank decodes
+its own stripe set of the same size (weak scaling, no data-path collective); the only
+torch.distributed calls are the barrier and the max-over-ranks of the elapsed time.  Rank 0
+prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (spec), GB/s
+
+WORKLOADS = {
+    # name: (generator, kwargs, signed, description)
+    "direct_w17": ("direct_w17", {}, True,
+                   "RLE v2 Direct, width 17, runs of 512, signed int64 (zigzag), seed 42"),
+    "delta_w10": ("delta_monotonic", {"width": 10}, True,
+                  "RLE v2 Delta, 10-bit deltas, runs of 512, monotonic int64, seed 43"),
+    "delta_w16": ("delta_monotonic", {"width": 16}, True,
+                  "RLE v2 Delta, 16-bit deltas, runs of 512, monotonic int64, seed 43"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="values per GPU per step")
+    ap.add_argument("--workload", default="direct_w17", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="target duration of the CPU baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run "
+                  "--nproc-per-node %d)" % (args.gpus, world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from bench_util import synth
+    from orc_format_amd import Context
+
+    gen_name, gen_kw, signed, desc = WORKLOADS[args.workload]
+    n_runs = max(1, args.rows // 512)
+    rows = n_runs * 512
+    # every rank decodes a different stripe set (seed offset by rank)
+    seed = {"direct_w17": 42, "delta_monotonic": 43}[gen_name] + 1000 * rank
+    stream, entries, expect = getattr(synth, gen_name)(n_runs, seed=seed, device="cuda", **gen_kw)
+    out = torch.empty(rows, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    stream_bytes = stream.numel()
+
+    ctx = Context(local_rank)
+
+    def step():
+        ctx.rlev2_device(stream.data_ptr(), stream_bytes, rows, signed, out.data_ptr(),
+                         entries.data_ptr(), entries.numel())
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    phase_ms = {1: 0.0, 2: 0.0, 3: 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for p in phase_ms:  # HIP events recorded on the context's stream around each phase
+            phase_ms[p] += ctx.phase_ms(p)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # parity of what was just timed: the decoded column equals the generator's values
+    if not torch.equal(out, expect):
+        bad = int((out != expect).sum().item())
+        raise SystemExit("bench.py: decoded column differs from the generator in %d values" % bad)
+
+    decoded_bytes = rows * 8
+    value = decoded_bytes * args.steps * world / elapsed / 1e9
+    k3_ms = phase_ms[3] / args.steps
+    algo_bytes = decoded_bytes + stream_bytes
+    achieved = algo_bytes / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
+
+    result = {
+        "metric": "device-resident decoded GB/s (RLEv2 int64 + strings) at 1/2/4/8 GPUs",
+        "value": round(value, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int64",
+        "data": "synthetic",
+        "config": {"workload": "%s: %d rows per GPU per step; %s" % (args.workload, rows, desc),
+                   "rows_per_gpu": rows, "stream_bytes_per_gpu": stream_bytes,
+                   "entry_points_per_gpu": int(entries.numel()), "parallelism": "stripe-sharded x%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "rlev2_values_kernel",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": algo_bytes,
+                     "avg_launch_ms": round(k3_ms, 4)},
+        "phases_ms": {"header_count_scan_readback": round(phase_ms[1] / args.steps, 4),
+                      "run_table_emit": round(phase_ms[2] / args.steps, 4),
+                      "value_expansion": round(k3_ms, 4)},
+        "decoded_frac_of_hbm_peak": round(value / world / HBM_PEAK_GBPS, 4),
+        "in_plus_out_GBps": round((decoded_bytes + stream_bytes) * args.steps * world / elapsed / 1e9, 2),
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, stream, rows, stream_bytes, signed, expect, np)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, stream, rows, stream_bytes, signed, expect, np):
+    """The CPU oracle (a C restatement of the reference's value-at-a-time decoder, not the Rust
+    crate itself) timed on the host cores over a bounded prefix of the same stream."""
+    import oracle_ctypes
+    oracle = oracle_ctypes.load()
+    bytes_per_value = stream_bytes / rows
+    # calibrate on 4M values, then size the sample for about --cpu-seconds of single-thread work
+    def run(n_vals):
+        n_vals = (n_vals // 512) * 512
+        nbytes = int(round(n_vals * bytes_per_value))
+        host = stream[:nbytes].cpu().numpy()
+        t0 = time.perf_counter()
+        rc, vals, _ = oracle.rlev2(host, n_vals, signed)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        assert (vals == expect[:n_vals].cpu().numpy()).all(), "oracle disagrees with the generator"
+        return n_vals, dt
+    n_cal, dt_cal = run(min(rows, 4 << 20))
+    n = int(min(rows, max(n_cal, n_cal * args.cpu_seconds / max(dt_cal, 1e-6))))
+    n, dt = run(n)
+    return {"value": round(n * 8 / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "first %d values (%.1f MB of stream) of the same column, single thread, "
+                      "%.1f s" % (n, n * bytes_per_value / 1e6, dt)}
+
+
+if __name__ == "__main__":
+    main()

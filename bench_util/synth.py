@@ -1,0 +1,131 @@
+"""Synthetic ORC streams built directly in GPU memory with torch tensor ops (bench / test
+plumbing -- not part of the decoder).
+
+Each generator returns the stream bytes, the run-header entry points a writer would record in
+the ROW_INDEX (one per `runs_per_entry` runs) and the values the stream encodes, all as CUDA
+tensors.  Streams are laid out exactly as the ORC v1 specification says; the small-size tests
+check them against the CPU oracle.
+"""
+import torch
+
+MASK64 = (1 << 64) - 1
+
+
+def _splitmix64(seed, start, count, device):
+    """splitmix64 of the counters start+1 .. start+count as int64 bit patterns."""
+    idx = torch.arange(start + 1, start + count + 1, dtype=torch.int64, device=device)
+    z = idx * _i64(0x9E3779B97F4A7C15) + _i64(seed)
+    z = (z ^ _lsr(z, 30)) * _i64(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * _i64(0x94D049BB133111EB)
+    return z ^ _lsr(z, 31)
+
+
+def _i64(u):
+    u &= MASK64
+    return u - (1 << 64) if u >= (1 << 63) else u
+
+
+def _lsr(x, k):
+    """logical shift right of int64 bit patterns"""
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+def pack_bits(values, width):
+    """values: int64 tensor [rows, n] of non-negative numbers < 2**width (width <= 56).
+    Returns uint8 [rows, ceil(n*width/8)]: every row packed MSB-first, zero padded."""
+    rows, n = values.shape
+    nbytes = (n * width + 7) // 8
+    # pad so that the "next value" gather below stays in range
+    v = torch.nn.functional.pad(values, (0, 2))
+    j = torch.arange(nbytes, device=values.device, dtype=torch.int64)
+    bit = j * 8
+    i = bit // width                      # first value overlapping byte j
+    off = bit - i * width                 # bits of value i already consumed
+    out = torch.zeros((rows, nbytes), dtype=torch.int64, device=values.device)
+    # a byte overlaps at most ceil(8/width)+1 values; accumulate them MSB-first
+    remaining = torch.full_like(j, 8)
+    cur_i, cur_off = i.clone(), off.clone()
+    for _ in range(8 // width + 2):
+        take = torch.minimum(remaining, width - cur_off)          # bits taken from value cur_i
+        vi = v[:, cur_i.clamp(max=n + 1)]                          # [rows, nbytes]
+        chunk = (vi >> (width - cur_off - take)) & ((torch.ones_like(take) << take) - 1)
+        out = (out << take) | chunk
+        remaining = remaining - take
+        cur_i = cur_i + 1
+        cur_off = torch.zeros_like(cur_off)
+        if int(remaining.max()) == 0:
+            break
+    return out.to(torch.uint8)
+
+
+def direct_w17(n_runs, seed=42, runs_per_entry=20, device="cuda", chunk_runs=1 << 15):
+    """Signed int64 column, every run Direct, 512 values of width 17 (header 61 ff): zigzag value
+    u ~ U[0, 2^17) with bit 16 forced so that the width is exactly 17.
+    Returns (stream uint8 [n_runs * 1090], entries int64, values int64 [n_runs * 512])."""
+    run_bytes = 2 + 1088
+    stream = torch.empty((n_runs, run_bytes), dtype=torch.uint8, device=device)
+    values = torch.empty((n_runs, 512), dtype=torch.int64, device=device)
+    stream[:, 0] = 0x61
+    stream[:, 1] = 0xFF
+    for r0 in range(0, n_runs, chunk_runs):
+        r1 = min(n_runs, r0 + chunk_runs)
+        u = _splitmix64(seed, r0 * 512, (r1 - r0) * 512, device)
+        u = (u & 0xFFFF) | 0x10000
+        u = u.view(r1 - r0, 512)
+        stream[r0:r1, 2:] = pack_bits(u, 17)
+        values[r0:r1] = (u >> 1) ^ -(u & 1)                        # zigzag decode
+    entries = torch.arange(0, n_runs, runs_per_entry, dtype=torch.int64, device=device) * run_bytes
+    return stream.view(-1), entries, values.view(-1)
+
+
+def delta_monotonic(n_runs, width=10, seed=43, runs_per_entry=20, device="cuda",
+                    chunk_runs=1 << 15, t0=1_600_000_000_000):
+    """Monotonic signed int64 column (timestamp-like): t[i] = t[i-1] + d, d ~ U[1, 1000] (seed),
+    every run Delta with 512 values and `width`-bit deltas (10: not byte aligned, 16: aligned).
+    The second value of each run uses d in [64, 1000] so that every header has the same size
+    (2 header bytes, 6-byte zigzag base, 2-byte delta base).
+    Returns (stream, entries, values)."""
+    assert width >= 10
+    payload = (510 * width + 7) // 8
+    run_bytes = 2 + 6 + 2 + payload
+    stream = torch.empty((n_runs, run_bytes), dtype=torch.uint8, device=device)
+    values = torch.empty((n_runs, 512), dtype=torch.int64, device=device)
+    code = {10: 9, 16: 15}[width]
+    stream[:, 0] = 0xC0 | (code << 1) | 1
+    stream[:, 1] = 0xFF
+    base = t0
+    for r0 in range(0, n_runs, chunk_runs):
+        r1 = min(n_runs, r0 + chunk_runs)
+        z = _splitmix64(seed, r0 * 512, (r1 - r0) * 512, device)
+        d = (_lsr(z, 11) % 1000 + 1).view(r1 - r0, 512)
+        d[:, 1] = d[:, 1] % 937 + 64
+        t = torch.cumsum(d.view(-1), 0).view(r1 - r0, 512) + base
+        base = int(t[-1, -1])
+        values[r0:r1] = t
+        zz = t[:, 0] << 1                                          # zigzag of a positive base
+        for k in range(6):                                         # 6-byte LEB128
+            stream[r0:r1, 2 + k] = (((zz >> (7 * k)) & 0x7F) | (0x80 if k < 5 else 0)).to(torch.uint8)
+        zd = d[:, 1] << 1
+        stream[r0:r1, 8] = ((zd & 0x7F) | 0x80).to(torch.uint8)
+        stream[r0:r1, 9] = ((zd >> 7) & 0x7F).to(torch.uint8)
+        stream[r0:r1, 10:] = pack_bits(d[:, 2:].contiguous(), width)
+    entries = torch.arange(0, n_runs, runs_per_entry, dtype=torch.int64, device=device) * run_bytes
+    return stream.view(-1), entries, values.view(-1)
+
+
+def string_lengths_w6(n_runs, seed=46, runs_per_entry=20, device="cuda", chunk_runs=1 << 15):
+    """Unsigned LENGTH stream of a direct-encoded string column: lengths ~ U[8, 56], Direct
+    runs of 512 values of width 6.  Returns (stream, entries, lengths int64)."""
+    run_bytes = 2 + 384
+    stream = torch.empty((n_runs, run_bytes), dtype=torch.uint8, device=device)
+    lengths = torch.empty((n_runs, 512), dtype=torch.int64, device=device)
+    stream[:, 0] = 0x40 | (5 << 1) | 1
+    stream[:, 1] = 0xFF
+    for r0 in range(0, n_runs, chunk_runs):
+        r1 = min(n_runs, r0 + chunk_runs)
+        z = _splitmix64(seed, r0 * 512, (r1 - r0) * 512, device)
+        ln = (_lsr(z, 11) % 49 + 8).view(r1 - r0, 512)
+        lengths[r0:r1] = ln
+        stream[r0:r1, 2:] = pack_bits(ln, 6)
+    entries = torch.arange(0, n_runs, runs_per_entry, dtype=torch.int64, device=device) * run_bytes
+    return stream.view(-1), entries, lengths.view(-1)

@@ -1,0 +1,238 @@
+/*
+ * orcd.h -- C ABI of the MI355X ORC stripe decoder (liborcd.so).
+ *
+ * The `orc-format` crate has no FFI layer: its decode boundary is the Rust API re-exported at
+ * src/read/decode/mod.rs:8-14 plus Column::get_stream (src/read/column.rs:38).  Every entry point
+ * below names the item of that API it replaces.  The crate's iterators pull values lazily from a
+ * `Read`; the entry points here are batch calls over one whole stream slice (what
+ * Column::get_stream returns), which is equivalent because every stream has its own reader.
+ *
+ * Conventions
+ *  - All functions return an ORCD_* status.  1..7 are the variants of `enum Error`
+ *    (src/error.rs:6-21) in declaration order; 100+ are conditions the crate answers with a panic.
+ *  - Pointers are plain host or device addresses as said by the ORCD_IN_DEVICE / ORCD_OUT_DEVICE
+ *    flags; the caller owns every input and output buffer.  The library owns only the context's
+ *    arena (run tables, staging), which grows on demand and is released by orcd_ctx_destroy.
+ *  - A context belongs to one thread and one GPU.  Work is enqueued on the context's HIP stream;
+ *    a decode call returns once its status is final (all validation happens in the header-scan
+ *    kernels, which the call waits for).  With ORCD_OUT_DEVICE the value kernels may still be
+ *    running on the stream when the call returns; with host outputs the call is synchronous.
+ *  - Decoding stops after `num_values` values; trailing stream bytes are ignored.
+ */
+#ifndef ORCD_H
+#define ORCD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (src/error.rs:6-21) ------------------------------------------------------ */
+enum {
+    ORCD_OK = 0,
+    ORCD_OUT_OF_SPEC = 1,
+    ORCD_INVALID_UTF8 = 2,
+    ORCD_INVALID_COLUMN = 3,
+    ORCD_INVALID_KIND = 4,
+    ORCD_DECODE_FLOAT = 5,
+    ORCD_DECOMPRESSION = 6,
+    ORCD_INVALID_PROTO = 7,
+    ORCD_UNSUPPORTED = 100, /* the crate panics with todo!() here (e.g. compressed files) */
+    ORCD_HIP_ERROR = 101,
+    ORCD_INVALID_ARGUMENT = 102
+};
+
+/* ---- flags ---------------------------------------------------------------------------------- */
+enum {
+    ORCD_SIGNED = 1u,      /* RLE v2: zigzag-decode values (SignedRleV2Iter) */
+    ORCD_IN_DEVICE = 2u,   /* stream / entry-point pointers are device memory */
+    ORCD_OUT_DEVICE = 4u,  /* output pointers are device memory */
+    ORCD_CHECK_UTF8 = 8u   /* strings: validate each value (tests/it/deserialize.rs:116-118) */
+};
+
+/* ---- stream kinds (src/proto.rs:127-136) and column encodings (src/proto.rs:149-154) -------- */
+enum {
+    ORCD_STREAM_PRESENT = 0, ORCD_STREAM_DATA = 1, ORCD_STREAM_LENGTH = 2,
+    ORCD_STREAM_DICTIONARY_DATA = 3, ORCD_STREAM_DICTIONARY_COUNT = 4, ORCD_STREAM_SECONDARY = 5,
+    ORCD_STREAM_ROW_INDEX = 6, ORCD_STREAM_BLOOM_FILTER = 7
+};
+enum { ORCD_ENC_DIRECT = 0, ORCD_ENC_DICTIONARY = 1, ORCD_ENC_DIRECT_V2 = 2, ORCD_ENC_DICTIONARY_V2 = 3 };
+
+typedef struct orcd_ctx orcd_ctx;
+
+/* Human-readable name of a status code. */
+const char *orcd_strerror(int status);
+
+/* ---- context -------------------------------------------------------------------------------- */
+
+/* Creates a decode context on GPU `device_id` with a HIP stream of its own.  Stands in for the
+ * `scratch: Vec<u8>` every reader of the crate takes and returns (src/read/column.rs:38,76;
+ * src/read/decode/rle_v2.rs:488-500): device buffers are recycled between calls. */
+int orcd_ctx_create(int device_id, orcd_ctx **ctx);
+int orcd_ctx_destroy(orcd_ctx *ctx);
+/* Makes the context enqueue on `hip_stream` (a hipStream_t, e.g. torch's current stream) instead
+ * of its own stream; NULL restores the context's stream. */
+int orcd_ctx_set_stream(orcd_ctx *ctx, void *hip_stream);
+/* Blocks until everything enqueued by this context has finished. */
+int orcd_ctx_synchronize(orcd_ctx *ctx);
+/* Duration in milliseconds of the GPU work of the most recent decode call on this context,
+ * measured with HIP events on the context's stream (waits for that work).  Negative on error. */
+float orcd_ctx_last_elapsed_ms(orcd_ctx *ctx);
+/* The same, per phase of the most recent decode call: 0 the whole call, 1 header count + segment
+ * prefix sums (including the read-back the host waits for), 2 run-table emission, 3 value
+ * expansion.  Negative when that phase did not run. */
+float orcd_ctx_phase_ms(orcd_ctx *ctx, int phase);
+/* Text of the last HIP runtime error seen by this context (after ORCD_HIP_ERROR). */
+const char *orcd_ctx_last_hip_error(orcd_ctx *ctx);
+
+/* ---- RLE v2 integers ------------------------------------------------------------------------ */
+
+/* Replaces SignedRleV2Iter::new(reader, length, scratch) / UnsignedRleV2Iter::new (and the run
+ * iterators they flatten): src/read/decode/rle_v2.rs:480-562, 677-758.
+ *
+ * Decodes `num_values` integers of an RLE v2 stream into out[0..num_values) as i64 (unsigned
+ * streams deliver the same 64 bits).  ShortRepeat, Direct, Delta and PatchedBase runs of every
+ * bit width of the ORC v1 specification are decoded.
+ *
+ * `entry_points` (nullable): ascending byte offsets inside the stream at which a run header
+ * starts -- for instance the stream positions of the column's ROW_INDEX entries.  They only add
+ * parallelism to the header scan (one lane walks the headers between two consecutive entries).
+ * The first entry is taken to be offset 0 whatever its value.  An entry that is not a run
+ * boundary yields ORCD_OUT_OF_SPEC. */
+int orcd_rlev2_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_values,
+                      const uint64_t *entry_points, size_t n_entries, int64_t *out,
+                      unsigned flags);
+
+/* One decoded run header as SignedRleV2RunIter / UnsignedRleV2RunIter expose it
+ * (src/read/decode/rle_v2.rs:432-439, 629-636: the Direct / Delta / ShortRepeat variants and
+ * their len()). */
+typedef struct {
+    uint64_t payload_offset; /* offset in the stream of the run's packed bytes */
+    uint64_t out_offset;     /* index of the run's first value in the decoded column */
+    uint32_t kind;           /* 0 ShortRepeat, 1 Direct, 2 PatchedBase, 3 Delta */
+    uint32_t bit_width;
+    uint32_t length;
+    uint32_t reserved;
+} orcd_run;
+
+/* Runs the header scan only and copies the run table to host memory: at most `max_runs` entries
+ * into `runs`, the run count needed to cover `num_values` into `n_runs`. */
+int orcd_rlev2_runs(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_values,
+                    const uint64_t *entry_points, size_t n_entries, orcd_run *runs,
+                    size_t max_runs, size_t *n_runs, unsigned flags);
+
+/* ---- byte-RLE and booleans ------------------------------------------------------------------ */
+
+/* Replaces BooleanRleRunIter (src/read/decode/boolean_rle.rs:14-63) expanded to its bytes:
+ * out[0..num_bytes).  `entry_points`: byte offsets of control bytes, as for orcd_rlev2_decode. */
+int orcd_byte_rle_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_bytes,
+                         const uint64_t *entry_points, size_t n_entries, uint8_t *out,
+                         unsigned flags);
+
+/* Replaces BooleanIter::new(reader, length) (src/read/decode/boolean_rle.rs:65-158) for PRESENT
+ * and boolean DATA streams.  Any of the three outputs may be NULL:
+ *   out_bytes  [num_bits]           one byte (0/1) per value, the layout of Vec<bool>;
+ *   out_bitmap [ceil(num_bits/8)]   least-significant-bit-first validity bitmap (Arrow layout);
+ *   set_bits   (always a HOST pointer) number of true values -- `num_of_values` of
+ *              tests/it/deserialize.rs:53. */
+int orcd_boolean_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_bits,
+                        const uint64_t *entry_points, size_t n_entries, uint8_t *out_bytes,
+                        uint8_t *out_bitmap, uint64_t *set_bits, unsigned flags);
+
+/* ---- floats --------------------------------------------------------------------------------- */
+
+/* Replaces FloatIter::<f32|f64, R>::new(reader, length) (src/read/decode/float.rs:34-91):
+ * `num_values` little-endian IEEE values of `elem_size` (4 or 8) bytes, copied bit-for-bit.
+ * A stream shorter than that yields ORCD_DECODE_FLOAT (float.rs:78-81). */
+int orcd_float_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t elem_size,
+                      size_t num_values, void *out, unsigned flags);
+
+/* ---- strings -------------------------------------------------------------------------------- */
+
+/* Replaces Values::new(reader, scratch) + Values::next(length) driven by an unsigned RLE v2
+ * LENGTH stream (src/read/decode/variable_length.rs:5-28; tests/it/deserialize.rs:106-140,
+ * 187-201).  Produces Arrow-style offsets[0..num_values] (offsets[num_values] = total bytes) and,
+ * when `bytes_out` is not NULL, the value bytes (offsets[num_values] of them) copied from
+ * `data`.  A LENGTH stream asking for more than `data_len` bytes yields ORCD_OUT_OF_SPEC; with
+ * ORCD_CHECK_UTF8 an ill-formed value yields ORCD_INVALID_UTF8. */
+int orcd_string_direct_decode(orcd_ctx *ctx, const uint8_t *length_stream, size_t length_len,
+                              const uint64_t *length_entry_points, size_t n_length_entries,
+                              const uint8_t *data, size_t data_len, size_t num_values,
+                              int64_t *offsets, uint8_t *bytes_out, unsigned flags);
+
+/* Replaces the gather of deserialize_str_dict_array (tests/it/deserialize.rs:142-185):
+ * value i = dictionary entry indices[i].  `dict_offsets` has dict_size + 1 entries.  Writes
+ * offsets_out[0..num_values]; when `bytes_out` is not NULL also the gathered bytes, of which
+ * there must be room for `bytes_capacity`.  An index >= dict_size yields ORCD_OUT_OF_SPEC
+ * (deserialize.rs:162).  All pointers follow ORCD_IN_DEVICE / ORCD_OUT_DEVICE. */
+int orcd_string_dictionary_decode(orcd_ctx *ctx, const int64_t *dict_offsets,
+                                  const uint8_t *dict_bytes, size_t dict_size,
+                                  const int64_t *indices, size_t num_values, int64_t *offsets_out,
+                                  uint8_t *bytes_out, size_t bytes_capacity, unsigned flags);
+
+/* ---- host side: file tail, stripe footers, column regions (no GPU involved) ------------------ */
+
+typedef struct orcd_file orcd_file;
+typedef struct orcd_stripe_footer orcd_stripe_footer;
+typedef struct orcd_column orcd_column;
+
+typedef struct { /* proto::StripeInformation, src/proto.rs:206-217 */
+    uint64_t offset, index_length, data_length, footer_length, number_of_rows;
+} orcd_stripe_info;
+
+typedef struct { /* proto::Stream, src/proto.rs:113-137, plus its resolved position */
+    uint32_t kind, column;
+    uint64_t length;
+    uint64_t offset; /* offset from the start of the stripe */
+} orcd_stream_info;
+
+/* Replaces read::read_metadata(&mut reader) -> FileMetadata (src/read/mod.rs:46-89).  Keeps the
+ * file open for the later region reads.  Unlike the crate, a tail larger than 16 KiB is re-read
+ * at its exact size instead of panicking. */
+int orcd_file_open(const char *path, orcd_file **file);
+/* Same, over a file image in host memory (borrowed: it must outlive the handle). */
+int orcd_file_open_memory(const uint8_t *bytes, size_t len, orcd_file **file);
+void orcd_file_close(orcd_file *file);
+/* FileMetadata accessors: footer.stripes.len(), footer.stripes[i], postscript.compression(),
+ * footer.number_of_rows, footer.types.len(), footer.types[i].kind / .subtypes. */
+size_t orcd_file_num_stripes(const orcd_file *file);
+int orcd_file_stripe(const orcd_file *file, size_t stripe, orcd_stripe_info *info);
+int orcd_file_compression(const orcd_file *file);
+uint64_t orcd_file_number_of_rows(const orcd_file *file);
+uint32_t orcd_file_row_index_stride(const orcd_file *file);
+size_t orcd_file_num_types(const orcd_file *file);
+int orcd_file_type_kind(const orcd_file *file, size_t type_id);
+
+/* Replaces read::read_stripe_footer(reader, &metadata, stripe, scratch) -> StripeFooter
+ * (src/read/mod.rs:95-111): one seek and one read. */
+int orcd_read_stripe_footer(orcd_file *file, size_t stripe, orcd_stripe_footer **footer);
+void orcd_stripe_footer_free(orcd_stripe_footer *footer);
+size_t orcd_stripe_footer_num_streams(const orcd_stripe_footer *footer);
+int orcd_stripe_footer_stream(const orcd_stripe_footer *footer, size_t i, orcd_stream_info *info);
+
+/* Replaces read::read_stripe_column(reader, &metadata, stripe, footer, column, scratch) -> Column
+ * (src/read/mod.rs:117-159): one seek and one read of the column's non-ROW_INDEX streams.  The
+ * footer is borrowed and must outlive the column.  An absent column yields ORCD_INVALID_COLUMN. */
+int orcd_read_stripe_column(orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
+                            uint32_t column, orcd_column **out);
+void orcd_column_free(orcd_column *column);
+/* Column::get_stream(kind, scratch) (src/read/column.rs:38-55): a borrowed view of the stream's
+ * bytes; ORCD_INVALID_KIND when the column has no such stream. */
+int orcd_column_get_stream(const orcd_column *column, int kind, const uint8_t **bytes,
+                           size_t *len);
+/* Column::encoding() / dictionary_size() / number_of_rows() (src/read/column.rs:58-72). */
+int orcd_column_encoding(const orcd_column *column, int *kind, uint32_t *dictionary_size);
+uint64_t orcd_column_number_of_rows(const orcd_column *column);
+/* Run-header entry points for orcd_rlev2_decode / orcd_byte_rle_decode taken from the column's
+ * ROW_INDEX stream (src/proto.rs:89-99), which the crate skips (src/read/mod.rs:136).  Reads the
+ * index stream on first use.  Returns a borrowed array (possibly empty) of ascending stream
+ * offsets for stream `kind`. */
+int orcd_column_entry_points(orcd_file *file, orcd_column *column, int kind,
+                             const uint64_t **entries, size_t *n_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

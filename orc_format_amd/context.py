@@ -1,0 +1,193 @@
+"""Decode context: one GPU, one HIP stream, recycled device buffers (orcd_ctx of include/orcd.h).
+
+The batch methods take host buffers (bytes / numpy) or raw device pointers (ints, e.g.
+`tensor.data_ptr()`), and call straight through the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .error import check
+
+
+def _host_u8(buf):
+    if isinstance(buf, np.ndarray):
+        return np.ascontiguousarray(buf.view(np.uint8) if buf.dtype != np.uint8 else buf)
+    return np.frombuffer(bytes(buf), dtype=np.uint8)
+
+
+def _entries(entry_points):
+    if entry_points is None or len(entry_points) == 0:
+        return None, 0
+    e = np.ascontiguousarray(entry_points, dtype=np.uint64)
+    return e, e.size
+
+
+class Context:
+    def __init__(self, device=0):
+        self._lib = N.lib()
+        self._h = C.c_void_p()
+        check(self._lib.orcd_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._lib.orcd_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, hip_stream):
+        check(self._lib.orcd_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)), self._h)
+
+    def synchronize(self):
+        check(self._lib.orcd_ctx_synchronize(self._h), self._h)
+
+    def last_elapsed_ms(self):
+        return float(self._lib.orcd_ctx_last_elapsed_ms(self._h))
+
+    def phase_ms(self, phase):
+        return float(self._lib.orcd_ctx_phase_ms(self._h, phase))
+
+    # ---- host-buffer calls ------------------------------------------------------------------
+    def rlev2(self, stream, num_values, signed, entry_points=None):
+        s = _host_u8(stream)
+        e, ne = _entries(entry_points)
+        out = np.empty(num_values, dtype=np.int64)
+        rc = self._lib.orcd_rlev2_decode(self._h, s.ctypes.data, s.size, num_values,
+                                         e.ctypes.data if ne else None, ne, out.ctypes.data,
+                                         N.SIGNED if signed else 0)
+        check(rc, self._h)
+        return out
+
+    def rlev2_runs(self, stream, num_values, signed=False, entry_points=None):
+        s = _host_u8(stream)
+        e, ne = _entries(entry_points)
+        cap = max(16, min(num_values, s.size))  # a run takes at least two stream bytes
+        arr = (N.OrcdRun * cap)()
+        cnt = C.c_size_t(0)
+        rc = self._lib.orcd_rlev2_runs(self._h, s.ctypes.data, s.size, num_values,
+                                       e.ctypes.data if ne else None, ne, arr, cap, C.byref(cnt),
+                                       N.SIGNED if signed else 0)
+        check(rc, self._h)
+        return [(r.kind, r.bit_width, r.length, r.out_offset, r.payload_offset)
+                for r in arr[:min(cap, cnt.value)]]
+
+    def byte_rle(self, stream, num_bytes, entry_points=None):
+        s = _host_u8(stream)
+        e, ne = _entries(entry_points)
+        out = np.empty(num_bytes, dtype=np.uint8)
+        rc = self._lib.orcd_byte_rle_decode(self._h, s.ctypes.data, s.size, num_bytes,
+                                            e.ctypes.data if ne else None, ne, out.ctypes.data, 0)
+        check(rc, self._h)
+        return out
+
+    def boolean(self, stream, num_bits, entry_points=None, want_bitmap=False):
+        s = _host_u8(stream)
+        e, ne = _entries(entry_points)
+        out = np.empty(num_bits, dtype=np.uint8)
+        bitmap = np.empty((num_bits + 7) // 8, dtype=np.uint8) if want_bitmap else None
+        ones = C.c_uint64(0)
+        rc = self._lib.orcd_boolean_decode(self._h, s.ctypes.data, s.size, num_bits,
+                                           e.ctypes.data if ne else None, ne, out.ctypes.data,
+                                           bitmap.ctypes.data if want_bitmap else None,
+                                           C.byref(ones), 0)
+        check(rc, self._h)
+        if want_bitmap:
+            return out.astype(bool), ones.value, bitmap
+        return out.astype(bool), ones.value
+
+    def floats(self, stream, num_values, dtype):
+        s = _host_u8(stream)
+        out = np.empty(num_values, dtype=dtype)
+        rc = self._lib.orcd_float_decode(self._h, s.ctypes.data, s.size, out.itemsize, num_values,
+                                         out.ctypes.data, 0)
+        check(rc, self._h)
+        return out
+
+    def string_direct(self, length_stream, data, num_values, check_utf8=True,
+                      length_entry_points=None):
+        ls, d = _host_u8(length_stream), _host_u8(data)
+        e, ne = _entries(length_entry_points)
+        offsets = np.empty(num_values + 1, dtype=np.int64)
+        out = np.empty(max(d.size, 1), dtype=np.uint8)
+        rc = self._lib.orcd_string_direct_decode(
+            self._h, ls.ctypes.data, ls.size, e.ctypes.data if ne else None, ne, d.ctypes.data,
+            d.size, num_values, offsets.ctypes.data, out.ctypes.data,
+            N.CHECK_UTF8 if check_utf8 else 0)
+        check(rc, self._h)
+        return offsets, out[:offsets[num_values]]
+
+    def string_dictionary(self, dict_offsets, dict_bytes, indices):
+        do = np.ascontiguousarray(dict_offsets, dtype=np.int64)
+        db = _host_u8(dict_bytes)
+        idx = np.ascontiguousarray(indices, dtype=np.int64)
+        n = idx.size
+        offsets = np.empty(n + 1, dtype=np.int64)
+        lens = np.diff(do)
+        cap = int(lens.max()) * n if n and lens.size else 0
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        rc = self._lib.orcd_string_dictionary_decode(
+            self._h, do.ctypes.data, db.ctypes.data, do.size - 1, idx.ctypes.data, n,
+            offsets.ctypes.data, out.ctypes.data, out.size, 0)
+        check(rc, self._h)
+        return offsets, out[:offsets[n]]
+
+    # ---- device-pointer calls (raw addresses) -------------------------------------------------
+    def rlev2_device(self, stream_ptr, length, num_values, signed, out_ptr, entries_ptr=0,
+                     n_entries=0):
+        rc = self._lib.orcd_rlev2_decode(self._h, stream_ptr, length, num_values,
+                                         entries_ptr or None, n_entries, out_ptr,
+                                         (N.SIGNED if signed else 0) | N.IN_DEVICE | N.OUT_DEVICE)
+        check(rc, self._h)
+
+    def boolean_device(self, stream_ptr, length, num_bits, out_bytes_ptr=0, out_bitmap_ptr=0,
+                       entries_ptr=0, n_entries=0, want_count=True):
+        ones = C.c_uint64(0)
+        rc = self._lib.orcd_boolean_decode(self._h, stream_ptr, length, num_bits,
+                                           entries_ptr or None, n_entries, out_bytes_ptr or None,
+                                           out_bitmap_ptr or None,
+                                           C.byref(ones) if want_count else None,
+                                           N.IN_DEVICE | N.OUT_DEVICE)
+        check(rc, self._h)
+        return ones.value
+
+    def float_device(self, stream_ptr, length, elem_size, num_values, out_ptr):
+        rc = self._lib.orcd_float_decode(self._h, stream_ptr, length, elem_size, num_values,
+                                         out_ptr, N.IN_DEVICE | N.OUT_DEVICE)
+        check(rc, self._h)
+
+    def string_direct_device(self, length_ptr, length_len, data_ptr, data_len, num_values,
+                             offsets_ptr, bytes_out_ptr=0, entries_ptr=0, n_entries=0,
+                             check_utf8=False):
+        rc = self._lib.orcd_string_direct_decode(
+            self._h, length_ptr, length_len, entries_ptr or None, n_entries, data_ptr, data_len,
+            num_values, offsets_ptr, bytes_out_ptr or None,
+            N.IN_DEVICE | N.OUT_DEVICE | (N.CHECK_UTF8 if check_utf8 else 0))
+        check(rc, self._h)
+
+
+_default = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device, created on first use."""
+    ctx = _default.get(device)
+    if ctx is None:
+        ctx = _default[device] = Context(device)
+    return ctx

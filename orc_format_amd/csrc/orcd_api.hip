@@ -1,0 +1,630 @@
+// C ABI of the decoder: context (stream, events, recycled device buffers) and the decode entry
+// points, which validate arguments, move host buffers when asked to, and chain the kernels.
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "orcd_internal.h"
+
+using namespace orcd;
+
+namespace {
+
+enum Slot {
+    SLOT_IN_A = 0,     // host stream staged on the device
+    SLOT_IN_B,         // second host input (string DATA, dictionary bytes)
+    SLOT_IN_ENTRIES,   // host entry points staged on the device
+    SLOT_IN_C,         // third host input (dictionary offsets / indices)
+    SLOT_IN_D,
+    SLOT_SEG_COUNT,
+    SLOT_SEG_OFF,
+    SLOT_TOTALS,
+    SLOT_RUNS,
+    SLOT_GROUPS,
+    SLOT_OUT_A,        // device staging of a host output
+    SLOT_OUT_B,
+    SLOT_PACKED,       // byte-RLE output feeding the boolean expansion
+    SLOT_SCAN_SUMS,
+    SLOT_FLAGS,
+    SLOT_TMP,
+    N_SLOTS
+};
+
+constexpr int N_EVENTS = 4;  // start, after header count + scan, after emit, after values
+
+}  // namespace
+
+struct orcd_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[N_EVENTS] = {};
+    bool ev_valid[N_EVENTS] = {};
+    void *slot[N_SLOTS] = {};
+    size_t cap[N_SLOTS] = {};
+    ScanTotals *h_totals = nullptr;  // pinned
+    uint64_t *h_scalars = nullptr;   // pinned, 8 words
+    hipError_t last_hip = hipSuccess;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                     \
+    do {                                       \
+        hipError_t e__ = (expr);               \
+        if (e__ != hipSuccess) {               \
+            (ctx)->last_hip = e__;             \
+            return ORCD_HIP_ERROR;             \
+        }                                      \
+    } while (0)
+
+#define ORCD_TRY(expr)                 \
+    do {                               \
+        int s__ = (expr);              \
+        if (s__ != ORCD_OK) return s__; \
+    } while (0)
+
+// Grows a recycled device buffer.  Earlier work on the stream may still read the old buffer, so
+// the stream is drained before it is released.
+int ensure(orcd_ctx *c, Slot s, size_t bytes, void **out) {
+    if (bytes == 0) bytes = 16;
+    if (c->cap[s] < bytes) {
+        if (c->slot[s]) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipFree(c->slot[s]));
+            c->slot[s] = nullptr;
+            c->cap[s] = 0;
+        }
+        size_t want = bytes + bytes / 4;
+        want = (want + 255) & ~(size_t)255;
+        HIP_TRY(c, hipMalloc(&c->slot[s], want));
+        c->cap[s] = want;
+    }
+    *out = c->slot[s];
+    return ORCD_OK;
+}
+
+// Device view of an input: the pointer itself, or a staged copy of host memory.
+int stage_in(orcd_ctx *c, Slot s, const void *p, size_t bytes, bool on_device, const void **dev) {
+    if (on_device) {
+        *dev = p;
+        return ORCD_OK;
+    }
+    void *d;
+    ORCD_TRY(ensure(c, s, bytes, &d));
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = d;
+    return ORCD_OK;
+}
+
+void mark(orcd_ctx *c, int i) {
+    if (hipEventRecord(c->ev[i], c->stream) == hipSuccess) c->ev_valid[i] = true;
+}
+
+void reset_events(orcd_ctx *c) {
+    for (int i = 0; i < N_EVENTS; i++) c->ev_valid[i] = false;
+}
+
+struct ScanResult {
+    const SegCount *seg_count;
+    const SegOffset *seg_off;
+    ScanTotals totals;
+};
+
+// Header count + segment prefix sums + read-back of the totals (the one host sync of a decode).
+template <typename CountFn>
+int count_and_scan(orcd_ctx *c, uint32_t n_seg, uint64_t num_values, CountFn count, ScanResult *res) {
+    void *seg_count, *seg_off, *totals;
+    ORCD_TRY(ensure(c, SLOT_SEG_COUNT, (size_t)n_seg * sizeof(SegCount), &seg_count));
+    ORCD_TRY(ensure(c, SLOT_SEG_OFF, (size_t)n_seg * sizeof(SegOffset), &seg_off));
+    ORCD_TRY(ensure(c, SLOT_TOTALS, sizeof(ScanTotals), &totals));
+    HIP_TRY(c, count((SegCount *)seg_count));
+    HIP_TRY(c, launch_segment_scan(c->stream, (const SegCount *)seg_count, n_seg, num_values,
+                                   (SegOffset *)seg_off, (ScanTotals *)totals));
+    HIP_TRY(c, hipMemcpyAsync(c->h_totals, totals, sizeof(ScanTotals), hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    res->seg_count = (const SegCount *)seg_count;
+    res->seg_off = (const SegOffset *)seg_off;
+    res->totals = *c->h_totals;
+    return ORCD_OK;
+}
+
+uint32_t segments_for(size_t n_entries) { return n_entries ? (uint32_t)n_entries : 1u; }
+
+struct Rlev2Table {
+    const RunEntry *runs;
+    const uint32_t *group_first;
+    uint32_t n_groups;
+    uint64_t total_runs;
+};
+
+// Builds the run table of one RLE v2 stream that is already on the device.
+int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
+                const uint64_t *d_entries, size_t n_entries, int is_signed, Rlev2Table *t) {
+    if (n_entries > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
+    const uint32_t n_seg = segments_for(n_entries);
+    const uint64_t *entries = n_entries ? d_entries : nullptr;
+    ScanResult sr;
+    ORCD_TRY(count_and_scan(c, n_seg, num_values, [&](SegCount *sc) {
+        return launch_rlev2_count(c->stream, d_stream, len, entries, n_seg, is_signed, sc);
+    }, &sr));
+    mark(c, 1);
+    if (sr.totals.error) return (int)sr.totals.error;
+    if (sr.totals.total_runs >= 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
+    const uint64_t n_slots = ((sr.totals.total_vals + WINDOW - 1) >> WINDOW_SHIFT) + 1;
+    if (n_slots > 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
+    void *runs, *groups;
+    ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(RunEntry), &runs));
+    ORCD_TRY(ensure(c, SLOT_GROUPS, (size_t)n_slots * sizeof(uint32_t), &groups));
+    HIP_TRY(c, launch_rlev2_emit(c->stream, d_stream, len, entries, n_seg, is_signed, sr.seg_count,
+                                 sr.seg_off, (RunEntry *)runs, (uint32_t *)groups,
+                                 (uint32_t)n_slots));
+    mark(c, 2);
+    const uint64_t covered = std::min<uint64_t>(num_values, sr.totals.total_vals);
+    t->runs = (const RunEntry *)runs;
+    t->group_first = (const uint32_t *)groups;
+    t->n_groups = (uint32_t)((covered + WINDOW - 1) >> WINDOW_SHIFT);
+    t->total_runs = sr.totals.total_runs;
+    return ORCD_OK;
+}
+
+// RLE v2 decode with device-side input and output.
+int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
+                 const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out) {
+    Rlev2Table t;
+    ORCD_TRY(rlev2_table(c, d_stream, len, num_values, d_entries, n_entries, is_signed, &t));
+    HIP_TRY(c, launch_rlev2_values(c->stream, d_stream, len, t.runs, t.group_first, t.n_groups,
+                                   num_values, is_signed, d_out));
+    mark(c, 3);
+    return ORCD_OK;
+}
+
+// Byte-RLE decode with device-side input and output.
+int byte_rle_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_bytes,
+                    const uint64_t *d_entries, size_t n_entries, uint8_t *d_out) {
+    if (n_entries > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
+    const uint32_t n_seg = segments_for(n_entries);
+    const uint64_t *entries = n_entries ? d_entries : nullptr;
+    ScanResult sr;
+    ORCD_TRY(count_and_scan(c, n_seg, num_bytes, [&](SegCount *sc) {
+        return launch_byte_rle_count(c->stream, d_stream, len, entries, n_seg, sc);
+    }, &sr));
+    mark(c, 1);
+    if (sr.totals.error) return (int)sr.totals.error;
+    if (sr.totals.total_runs >= 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
+    void *runs;
+    ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(ByteRun), &runs));
+    HIP_TRY(c, launch_byte_rle_emit(c->stream, d_stream, len, entries, n_seg, sr.seg_count,
+                                    sr.seg_off, (ByteRun *)runs));
+    mark(c, 2);
+    HIP_TRY(c, launch_byte_rle_expand(c->stream, d_stream, (const ByteRun *)runs,
+                                      sr.totals.total_runs, num_bytes, d_out));
+    mark(c, 3);
+    return ORCD_OK;
+}
+
+int copy_out(orcd_ctx *c, void *host, const void *dev, size_t bytes) {
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ORCD_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char *orcd_strerror(int status) {
+    switch (status) {
+    case ORCD_OK: return "ok";
+    case ORCD_OUT_OF_SPEC: return "out of spec";
+    case ORCD_INVALID_UTF8: return "invalid utf-8";
+    case ORCD_INVALID_COLUMN: return "invalid column";
+    case ORCD_INVALID_KIND: return "invalid stream kind for column";
+    case ORCD_DECODE_FLOAT: return "failed to decode float";
+    case ORCD_DECOMPRESSION: return "decompression failed";
+    case ORCD_INVALID_PROTO: return "invalid protobuf";
+    case ORCD_UNSUPPORTED: return "unsupported feature";
+    case ORCD_HIP_ERROR: return "HIP runtime error";
+    case ORCD_INVALID_ARGUMENT: return "invalid argument";
+    default: return "unknown status";
+    }
+}
+
+int orcd_ctx_create(int device_id, orcd_ctx **out) {
+    if (!out) return ORCD_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return ORCD_HIP_ERROR;
+    DeviceGuard g(device_id);
+    orcd_ctx *c = new orcd_ctx();
+    c->device = device_id;
+    bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < N_EVENTS; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_totals, sizeof(ScanTotals), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_scalars, 8 * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        orcd_ctx_destroy(c);
+        return ORCD_HIP_ERROR;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return ORCD_OK;
+}
+
+int orcd_ctx_destroy(orcd_ctx *c) {
+    if (!c) return ORCD_OK;
+    DeviceGuard g(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < N_SLOTS; i++)
+        if (c->slot[i]) (void)hipFree(c->slot[i]);
+    for (int i = 0; i < N_EVENTS; i++)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->h_totals) (void)hipHostFree(c->h_totals);
+    if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return ORCD_OK;
+}
+
+int orcd_ctx_set_stream(orcd_ctx *c, void *hip_stream) {
+    if (!c) return ORCD_INVALID_ARGUMENT;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return ORCD_OK;
+}
+
+int orcd_ctx_synchronize(orcd_ctx *c) {
+    if (!c) return ORCD_INVALID_ARGUMENT;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ORCD_OK;
+}
+
+float orcd_ctx_phase_ms(orcd_ctx *c, int phase) {
+    if (!c || phase < 0 || phase >= N_EVENTS) return -1.0f;
+    DeviceGuard g(c->device);
+    int last = N_EVENTS - 1;
+    while (last > 0 && !c->ev_valid[last]) last--;
+    if (!c->ev_valid[0] || last == 0) return -1.0f;
+    int a = 0, b = last;
+    if (phase > 0) {
+        if (!c->ev_valid[phase] || !c->ev_valid[phase - 1]) return -1.0f;
+        a = phase - 1;
+        b = phase;
+    }
+    if (hipEventSynchronize(c->ev[b]) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+float orcd_ctx_last_elapsed_ms(orcd_ctx *c) { return orcd_ctx_phase_ms(c, 0); }
+
+const char *orcd_ctx_last_hip_error(orcd_ctx *c) {
+    return c ? hipGetErrorString(c->last_hip) : "no context";
+}
+
+// ---- RLE v2 ---------------------------------------------------------------------------------
+
+int orcd_rlev2_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_values,
+                      const uint64_t *entry_points, size_t n_entries, int64_t *out,
+                      unsigned flags) {
+    if (!c || (len && !stream) || (num_values && !out) || (n_entries && !entry_points))
+        return ORCD_INVALID_ARGUMENT;
+    if (num_values == 0) return ORCD_OK;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    mark(c, 0);
+    const void *d_stream, *d_entries;
+    ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t), in_dev, &d_entries));
+    int64_t *d_out = out;
+    if (!out_dev) {
+        void *p;
+        ORCD_TRY(ensure(c, SLOT_OUT_A, num_values * sizeof(int64_t), &p));
+        d_out = (int64_t *)p;
+    }
+    ORCD_TRY(rlev2_device(c, (const uint8_t *)d_stream, len, num_values, (const uint64_t *)d_entries,
+                          n_entries, (flags & ORCD_SIGNED) ? 1 : 0, d_out));
+    if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, num_values * sizeof(int64_t)));
+    return ORCD_OK;
+}
+
+int orcd_rlev2_runs(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_values,
+                    const uint64_t *entry_points, size_t n_entries, orcd_run *runs,
+                    size_t max_runs, size_t *n_runs, unsigned flags) {
+    if (!c || (len && !stream) || !n_runs || (max_runs && !runs) || (n_entries && !entry_points))
+        return ORCD_INVALID_ARGUMENT;
+    *n_runs = 0;
+    if (num_values == 0) return ORCD_OK;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE;
+    mark(c, 0);
+    const void *d_stream, *d_entries;
+    ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t), in_dev, &d_entries));
+    Rlev2Table t;
+    ORCD_TRY(rlev2_table(c, (const uint8_t *)d_stream, len, num_values, (const uint64_t *)d_entries,
+                         n_entries, (flags & ORCD_SIGNED) ? 1 : 0, &t));
+    RunEntry *h = new RunEntry[t.total_runs + 1];
+    hipError_t e = hipMemcpyAsync(h, t.runs, (t.total_runs + 1) * sizeof(RunEntry),
+                                  hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        delete[] h;
+        c->last_hip = e;
+        return ORCD_HIP_ERROR;
+    }
+    size_t count = 0;
+    for (uint64_t i = 0; i < t.total_runs && h[i].out_off < num_values; i++, count++) {
+        if (count < max_runs) {
+            runs[count].payload_offset = desc_payload(h[i].desc);
+            runs[count].out_offset = h[i].out_off;
+            runs[count].kind = desc_kind(h[i].desc);
+            runs[count].bit_width = desc_width(h[i].desc);
+            runs[count].length = desc_len(h[i].desc);
+            runs[count].reserved = 0;
+        }
+    }
+    delete[] h;
+    *n_runs = count;
+    return ORCD_OK;
+}
+
+// ---- byte-RLE and booleans ------------------------------------------------------------------
+
+int orcd_byte_rle_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_bytes,
+                         const uint64_t *entry_points, size_t n_entries, uint8_t *out,
+                         unsigned flags) {
+    if (!c || (len && !stream) || (num_bytes && !out) || (n_entries && !entry_points))
+        return ORCD_INVALID_ARGUMENT;
+    if (num_bytes == 0) return ORCD_OK;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    mark(c, 0);
+    const void *d_stream, *d_entries;
+    ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t), in_dev, &d_entries));
+    uint8_t *d_out = out;
+    if (!out_dev) {
+        void *p;
+        ORCD_TRY(ensure(c, SLOT_OUT_A, num_bytes, &p));
+        d_out = (uint8_t *)p;
+    }
+    ORCD_TRY(byte_rle_device(c, (const uint8_t *)d_stream, len, num_bytes, (const uint64_t *)d_entries,
+                             n_entries, d_out));
+    if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, num_bytes));
+    return ORCD_OK;
+}
+
+int orcd_boolean_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_bits,
+                        const uint64_t *entry_points, size_t n_entries, uint8_t *out_bytes,
+                        uint8_t *out_bitmap, uint64_t *set_bits, unsigned flags) {
+    if (!c || (len && !stream) || (n_entries && !entry_points)) return ORCD_INVALID_ARGUMENT;
+    if (set_bits) *set_bits = 0;
+    if (num_bits == 0) return ORCD_OK;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    const size_t n_bytes = (num_bits + 7) / 8;
+    mark(c, 0);
+    const void *d_stream, *d_entries;
+    ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t), in_dev, &d_entries));
+    void *packed, *flagbuf;
+    ORCD_TRY(ensure(c, SLOT_PACKED, n_bytes, &packed));
+    ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flagbuf));
+    ORCD_TRY(byte_rle_device(c, (const uint8_t *)d_stream, len, n_bytes, (const uint64_t *)d_entries,
+                             n_entries, (uint8_t *)packed));
+    uint8_t *d_bytes = out_bytes, *d_bitmap = out_bitmap;
+    if (!out_dev) {
+        void *p;
+        if (out_bytes) {
+            ORCD_TRY(ensure(c, SLOT_OUT_A, num_bits, &p));
+            d_bytes = (uint8_t *)p;
+        }
+        if (out_bitmap) {
+            ORCD_TRY(ensure(c, SLOT_OUT_B, n_bytes, &p));
+            d_bitmap = (uint8_t *)p;
+        }
+    }
+    uint64_t *d_count = set_bits ? (uint64_t *)flagbuf : nullptr;
+    if (d_count) HIP_TRY(c, hipMemsetAsync(d_count, 0, sizeof(uint64_t), c->stream));
+    if (d_bytes || d_bitmap || d_count)
+        HIP_TRY(c, launch_bool_expand(c->stream, (const uint8_t *)packed, num_bits, d_bytes, d_bitmap, d_count));
+    mark(c, 3);
+    if (d_count)
+        HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_count, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (!out_dev) {
+        if (out_bytes) HIP_TRY(c, hipMemcpyAsync(out_bytes, d_bytes, num_bits, hipMemcpyDeviceToHost, c->stream));
+        if (out_bitmap) HIP_TRY(c, hipMemcpyAsync(out_bitmap, d_bitmap, n_bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (d_count || !out_dev) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (set_bits) *set_bits = c->h_scalars[0];
+    return ORCD_OK;
+}
+
+// ---- floats ---------------------------------------------------------------------------------
+
+int orcd_float_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t elem_size,
+                      size_t num_values, void *out, unsigned flags) {
+    if (!c || (len && !stream) || (num_values && !out)) return ORCD_INVALID_ARGUMENT;
+    if (elem_size != 4 && elem_size != 8) return ORCD_INVALID_ARGUMENT;
+    if (num_values > len / elem_size) return ORCD_DECODE_FLOAT;  // float.rs:78-81
+    if (num_values == 0) return ORCD_OK;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    const size_t bytes = num_values * elem_size;
+    mark(c, 0);
+    // little-endian IEEE in the file, little-endian IEEE on the GPU: a bit-for-bit copy
+    hipMemcpyKind kind = in_dev ? (out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost)
+                                : (out_dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost);
+    HIP_TRY(c, hipMemcpyAsync(out, stream, bytes, kind, c->stream));
+    mark(c, 3);
+    if (!out_dev) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ORCD_OK;
+}
+
+// ---- strings --------------------------------------------------------------------------------
+
+int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t length_len,
+                              const uint64_t *length_entry_points, size_t n_length_entries,
+                              const uint8_t *data, size_t data_len, size_t num_values,
+                              int64_t *offsets, uint8_t *bytes_out, unsigned flags) {
+    if (!c || !offsets || (length_len && !length_stream) || (data_len && !data) ||
+        (n_length_entries && !length_entry_points))
+        return ORCD_INVALID_ARGUMENT;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    mark(c, 0);
+    int64_t *d_offsets = offsets;
+    if (!out_dev) {
+        void *p;
+        ORCD_TRY(ensure(c, SLOT_OUT_A, (num_values + 1) * sizeof(int64_t), &p));
+        d_offsets = (int64_t *)p;
+    }
+    if (num_values) {
+        const void *d_len_stream, *d_entries;
+        ORCD_TRY(stage_in(c, SLOT_IN_A, length_stream, length_len, in_dev, &d_len_stream));
+        ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, length_entry_points, n_length_entries * sizeof(uint64_t),
+                          in_dev, &d_entries));
+        // lengths land in offsets[0..n), then become offsets by an in-place exclusive prefix sum
+        ORCD_TRY(rlev2_device(c, (const uint8_t *)d_len_stream, length_len, num_values,
+                              (const uint64_t *)d_entries, n_length_entries, 0, d_offsets));
+    }
+    void *sums;
+    ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(num_values) * sizeof(uint64_t), &sums));
+    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)d_offsets, num_values, (uint64_t *)sums));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_offsets + num_values, sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint64_t total = c->h_scalars[0];
+    if (total > data_len) return ORCD_OUT_OF_SPEC;  // Values::next would run out of bytes
+    const uint8_t *d_data = data;
+    uint8_t *d_bytes = bytes_out;
+    const bool want_utf8 = (flags & ORCD_CHECK_UTF8) && total;
+    if (total && (bytes_out || want_utf8)) {
+        if (!in_dev) {
+            const void *p;
+            ORCD_TRY(stage_in(c, SLOT_IN_B, data, total, false, &p));
+            d_data = (const uint8_t *)p;
+        }
+        if (bytes_out) {
+            if (!out_dev) {
+                d_bytes = const_cast<uint8_t *>(d_data);  // the staged copy is the result
+                if (in_dev) {
+                    void *p;
+                    ORCD_TRY(ensure(c, SLOT_OUT_B, total, &p));
+                    d_bytes = (uint8_t *)p;
+                }
+            }
+            if (d_bytes != d_data)
+                HIP_TRY(c, hipMemcpyAsync(d_bytes, d_data, total, hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (want_utf8) {
+            void *flag;
+            ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
+            HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
+            HIP_TRY(c, launch_utf8_validate(c->stream, d_data, d_offsets, num_values, (uint32_t *)flag, total));
+            HIP_TRY(c, hipMemcpyAsync(c->h_scalars, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (*(uint32_t *)c->h_scalars) return ORCD_INVALID_UTF8;
+        }
+    }
+    mark(c, 3);
+    if (!out_dev) {
+        HIP_TRY(c, hipMemcpyAsync(offsets, d_offsets, (num_values + 1) * sizeof(int64_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+        if (bytes_out && total)
+            HIP_TRY(c, hipMemcpyAsync(bytes_out, d_bytes, total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return ORCD_OK;
+}
+
+int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
+                                  const uint8_t *dict_bytes, size_t dict_size,
+                                  const int64_t *indices, size_t num_values, int64_t *offsets_out,
+                                  uint8_t *bytes_out, size_t bytes_capacity, unsigned flags) {
+    if (!c || !offsets_out || !dict_offsets || (num_values && !indices)) return ORCD_INVALID_ARGUMENT;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    mark(c, 0);
+    size_t dict_total = 0;
+    const void *d_dict_off, *d_dict_bytes, *d_idx;
+    ORCD_TRY(stage_in(c, SLOT_IN_C, dict_offsets, (dict_size + 1) * sizeof(int64_t), in_dev, &d_dict_off));
+    if (in_dev) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_scalars, dict_offsets + dict_size, sizeof(int64_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dict_total = (size_t)c->h_scalars[0];
+    } else {
+        dict_total = (size_t)dict_offsets[dict_size];
+    }
+    if (dict_total && !dict_bytes) return ORCD_INVALID_ARGUMENT;
+    ORCD_TRY(stage_in(c, SLOT_IN_B, dict_bytes, dict_total, in_dev, &d_dict_bytes));
+    ORCD_TRY(stage_in(c, SLOT_IN_D, indices, num_values * sizeof(int64_t), in_dev, &d_idx));
+    int64_t *d_offsets = offsets_out;
+    if (!out_dev) {
+        void *p;
+        ORCD_TRY(ensure(c, SLOT_OUT_A, (num_values + 1) * sizeof(int64_t), &p));
+        d_offsets = (int64_t *)p;
+    }
+    void *flag, *sums;
+    ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
+    ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(num_values) * sizeof(uint64_t), &sums));
+    HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, launch_dictionary_lengths(c->stream, (const int64_t *)d_dict_off, dict_size,
+                                         (const int64_t *)d_idx, num_values, (uint64_t *)d_offsets,
+                                         (uint32_t *)flag));
+    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)d_offsets, num_values, (uint64_t *)sums));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_offsets + num_values, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (*(uint32_t *)(c->h_scalars + 1)) return ORCD_OUT_OF_SPEC;
+    const uint64_t total = c->h_scalars[0];
+    uint8_t *d_bytes = bytes_out;
+    if (bytes_out) {
+        if (total > bytes_capacity) return ORCD_INVALID_ARGUMENT;
+        if (!out_dev) {
+            void *p;
+            ORCD_TRY(ensure(c, SLOT_OUT_B, total, &p));
+            d_bytes = (uint8_t *)p;
+        }
+        HIP_TRY(c, launch_dictionary_gather(c->stream, (const int64_t *)d_dict_off,
+                                            (const uint8_t *)d_dict_bytes, (const int64_t *)d_idx,
+                                            num_values, d_offsets, d_bytes));
+    }
+    mark(c, 3);
+    if (!out_dev) {
+        HIP_TRY(c, hipMemcpyAsync(offsets_out, d_offsets, (num_values + 1) * sizeof(int64_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+        if (bytes_out && total)
+            HIP_TRY(c, hipMemcpyAsync(bytes_out, d_bytes, total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return ORCD_OK;
+}
+
+}  // extern "C"

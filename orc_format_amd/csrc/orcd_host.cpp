@@ -1,0 +1,499 @@
+// Host side of the decoder: ORC file tail, stripe footers and column regions.
+//
+// Mirrors read_metadata / read_stripe_footer / read_stripe_column / Column of the orc-format crate
+// (src/read/mod.rs:46-159, src/read/column.rs:11-79) with a hand-written reader for the handful of
+// protobuf messages involved (src/proto.rs:89-99, 113-164, 166-217, 236-278).  No GPU code here.
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/orcd.h"
+
+namespace {
+
+constexpr uint64_t DEFAULT_FOOTER_SIZE = 16 * 1024;  // src/read/mod.rs:22
+
+// ---- protobuf wire format --------------------------------------------------------------------
+
+struct Cursor {
+    const uint8_t *p;
+    const uint8_t *end;
+    bool ok = true;
+
+    bool done() const { return !ok || p >= end; }
+    uint64_t varint() {
+        uint64_t v = 0;
+        for (int shift = 0; shift < 70; shift += 7) {
+            if (p >= end) break;
+            const uint8_t b = *p++;
+            v |= (uint64_t)(b & 0x7F) << (shift & 63);
+            if (b < 0x80) return v;
+        }
+        ok = false;
+        return 0;
+    }
+    // next field: number, wire type; for length-delimited fields `sub` spans the payload and for
+    // varints `value` holds it.  Fixed-width fields are skipped.
+    bool next(uint32_t &field, uint32_t &wire, uint64_t &value, Cursor &sub) {
+        if (done()) return false;
+        const uint64_t key = varint();
+        if (!ok) return false;
+        field = (uint32_t)(key >> 3);
+        wire = (uint32_t)(key & 7);
+        value = 0;
+        switch (wire) {
+        case 0: value = varint(); break;
+        case 1: if (end - p < 8) ok = false; else p += 8; break;
+        case 5: if (end - p < 4) ok = false; else p += 4; break;
+        case 2: {
+            const uint64_t n = varint();
+            if (!ok || (uint64_t)(end - p) < n) { ok = false; break; }
+            sub.p = p;
+            sub.end = p + n;
+            sub.ok = true;
+            p += n;
+            break;
+        }
+        default: ok = false;
+        }
+        return ok;
+    }
+};
+
+// repeated uint32/uint64, packed or not
+void read_repeated(uint32_t wire, uint64_t value, Cursor sub, std::vector<uint64_t> &out, bool &ok) {
+    if (wire == 0) {
+        out.push_back(value);
+    } else if (wire == 2) {
+        while (!sub.done()) out.push_back(sub.varint());
+        ok = ok && sub.ok;
+    } else {
+        ok = false;
+    }
+}
+
+struct TypeInfo {
+    int kind = 0;
+    std::vector<uint64_t> subtypes;
+};
+
+struct Encoding {
+    int kind = 0;
+    bool has_dict = false;
+    uint32_t dictionary_size = 0;
+};
+
+// ---- byte source: a file or a borrowed memory image --------------------------------------------
+
+struct Source {
+    FILE *f = nullptr;
+    const uint8_t *mem = nullptr;
+    uint64_t len = 0;
+
+    bool read_at(uint64_t off, uint64_t n, std::vector<uint8_t> &out) const {
+        if (off > len || n > len - off) return false;
+        out.resize(n);
+        if (n == 0) return true;
+        if (mem) {
+            memcpy(out.data(), mem + off, n);
+            return true;
+        }
+        if (fseeko(f, (off_t)off, SEEK_SET) != 0) return false;
+        return fread(out.data(), 1, n, f) == n;
+    }
+};
+
+}  // namespace
+
+struct orcd_file {
+    Source src;
+    int compression = 0;
+    uint64_t number_of_rows = 0;
+    uint32_t row_index_stride = 0;
+    std::vector<orcd_stripe_info> stripes;
+    std::vector<TypeInfo> types;
+};
+
+struct orcd_stripe_footer {
+    std::vector<orcd_stream_info> streams;
+    std::vector<Encoding> columns;
+    size_t stripe = 0;
+};
+
+struct orcd_column {
+    std::vector<uint8_t> data;  // all non-ROW_INDEX streams of the column, in file order
+    uint32_t column = 0;
+    uint64_t number_of_rows = 0;
+    size_t stripe = 0;
+    const orcd_stripe_footer *footer = nullptr;
+    // entry points per stream kind, filled on demand from the ROW_INDEX stream
+    bool index_loaded = false;
+    std::vector<uint64_t> entries[8];
+};
+
+namespace {
+
+int parse_tail(orcd_file *f) {
+    const Source &s = f->src;
+    if (s.len < 4) return ORCD_OUT_OF_SPEC;
+    // initial read of the tail (src/read/mod.rs:53-61)
+    uint64_t tail_len = std::min<uint64_t>(s.len, DEFAULT_FOOTER_SIZE);
+    std::vector<uint8_t> tail;
+    if (!s.read_at(s.len - tail_len, tail_len, tail)) return ORCD_OUT_OF_SPEC;
+    const uint64_t ps_len = tail.back();  // src/read/mod.rs:65
+    if (ps_len + 1 > tail_len) return ORCD_OUT_OF_SPEC;
+    uint64_t footer_length = 0, metadata_length = 0;
+    bool has_footer_length = false;
+    {
+        Cursor c{tail.data() + tail_len - 1 - ps_len, tail.data() + tail_len - 1};
+        uint32_t field, wire;
+        uint64_t v;
+        Cursor sub{nullptr, nullptr};
+        while (c.next(field, wire, v, sub)) {
+            if (wire != 0) continue;
+            if (field == 1) { footer_length = v; has_footer_length = true; }
+            else if (field == 2) f->compression = (int)v;
+            else if (field == 5) metadata_length = v;
+        }
+        if (!c.ok) return ORCD_INVALID_PROTO;
+    }
+    if (!has_footer_length) return ORCD_OUT_OF_SPEC;  // src/read/mod.rs:73
+    if (f->compression != 0) return ORCD_UNSUPPORTED;  // only CompressionKind::None is decoded
+    const uint64_t need = 1 + ps_len + footer_length + metadata_length;
+    if (need > s.len) return ORCD_OUT_OF_SPEC;
+    if (need > tail_len) {  // the crate panics here; re-read the tail at its exact size
+        tail_len = need;
+        if (!s.read_at(s.len - tail_len, tail_len, tail)) return ORCD_OUT_OF_SPEC;
+    }
+    const uint8_t *footer_end = tail.data() + tail_len - 1 - ps_len;
+    Cursor c{footer_end - footer_length, footer_end};
+    uint32_t field, wire;
+    uint64_t v;
+    Cursor sub{nullptr, nullptr};
+    while (c.next(field, wire, v, sub)) {
+        if (field == 3 && wire == 2) {  // StripeInformation
+            orcd_stripe_info si = {0, 0, 0, 0, 0};
+            uint32_t f2, w2;
+            uint64_t v2;
+            Cursor s2{nullptr, nullptr};
+            while (sub.next(f2, w2, v2, s2)) {
+                if (w2 != 0) continue;
+                if (f2 == 1) si.offset = v2;
+                else if (f2 == 2) si.index_length = v2;
+                else if (f2 == 3) si.data_length = v2;
+                else if (f2 == 4) si.footer_length = v2;
+                else if (f2 == 5) si.number_of_rows = v2;
+            }
+            if (!sub.ok) return ORCD_INVALID_PROTO;
+            f->stripes.push_back(si);
+        } else if (field == 4 && wire == 2) {  // Type
+            TypeInfo t;
+            uint32_t f2, w2;
+            uint64_t v2;
+            Cursor s2{nullptr, nullptr};
+            bool ok = true;
+            while (sub.next(f2, w2, v2, s2)) {
+                if (f2 == 1 && w2 == 0) t.kind = (int)v2;
+                else if (f2 == 2) read_repeated(w2, v2, s2, t.subtypes, ok);
+            }
+            if (!sub.ok || !ok) return ORCD_INVALID_PROTO;
+            f->types.push_back(t);
+        } else if (field == 6 && wire == 0) {
+            f->number_of_rows = v;
+        } else if (field == 8 && wire == 0) {
+            f->row_index_stride = (uint32_t)v;
+        }
+    }
+    if (!c.ok) return ORCD_INVALID_PROTO;
+    return ORCD_OK;
+}
+
+int parse_stripe_footer(const std::vector<uint8_t> &buf, orcd_stripe_footer *out) {
+    Cursor c{buf.data(), buf.data() + buf.size()};
+    uint32_t field, wire;
+    uint64_t v;
+    Cursor sub{nullptr, nullptr};
+    uint64_t offset = 0;
+    while (c.next(field, wire, v, sub)) {
+        if (field == 1 && wire == 2) {  // Stream
+            orcd_stream_info si = {0, 0, 0, 0};
+            uint32_t f2, w2;
+            uint64_t v2;
+            Cursor s2{nullptr, nullptr};
+            while (sub.next(f2, w2, v2, s2)) {
+                if (w2 != 0) continue;
+                if (f2 == 1) si.kind = (uint32_t)v2;
+                else if (f2 == 2) si.column = (uint32_t)v2;
+                else if (f2 == 3) si.length = v2;
+            }
+            if (!sub.ok) return ORCD_INVALID_PROTO;
+            si.offset = offset;  // streams are laid out back to back (src/read/mod.rs:127-138)
+            offset += si.length;
+            out->streams.push_back(si);
+        } else if (field == 2 && wire == 2) {  // ColumnEncoding
+            Encoding e;
+            uint32_t f2, w2;
+            uint64_t v2;
+            Cursor s2{nullptr, nullptr};
+            while (sub.next(f2, w2, v2, s2)) {
+                if (w2 != 0) continue;
+                if (f2 == 1) e.kind = (int)v2;
+                else if (f2 == 2) { e.has_dict = true; e.dictionary_size = (uint32_t)v2; }
+            }
+            if (!sub.ok) return ORCD_INVALID_PROTO;
+            out->columns.push_back(e);
+        }
+    }
+    return c.ok ? ORCD_OK : ORCD_INVALID_PROTO;
+}
+
+// How many ROW_INDEX positions each stream of a column consumes when the file is uncompressed:
+// RLE v2 -> (byte offset, values to skip); byte-RLE -> (byte offset, bytes to skip);
+// boolean -> byte-RLE + (bits to skip); raw bytes -> (byte offset).
+enum PosShape { POS_RLEV2 = 2, POS_BYTE_RLE = 2, POS_BOOLEAN = 3, POS_RAW = 1 };
+
+int positions_of(int type_kind, int encoding, uint32_t stream_kind) {
+    if (stream_kind == ORCD_STREAM_PRESENT) return POS_BOOLEAN;
+    switch (type_kind) {
+    case 0: return stream_kind == ORCD_STREAM_DATA ? POS_BOOLEAN : -1;                 // boolean
+    case 1: return stream_kind == ORCD_STREAM_DATA ? POS_BYTE_RLE : -1;                // tinyint
+    case 2: case 3: case 4: case 15:                                                   // ints, date
+        return stream_kind == ORCD_STREAM_DATA ? POS_RLEV2 : -1;
+    case 5: case 6: return stream_kind == ORCD_STREAM_DATA ? POS_RAW : -1;             // float, double
+    case 7: case 16: case 17: case 8:                                                  // string-like, binary
+        if (encoding == ORCD_ENC_DICTIONARY_V2 || encoding == ORCD_ENC_DICTIONARY) {
+            // DATA (indices) is positioned; the dictionary streams are not
+            return stream_kind == ORCD_STREAM_DATA ? POS_RLEV2 : 0;
+        }
+        if (stream_kind == ORCD_STREAM_DATA) return POS_RAW;
+        if (stream_kind == ORCD_STREAM_LENGTH) return POS_RLEV2;
+        return -1;
+    default: return -1;
+    }
+}
+
+int load_entry_points(orcd_file *file, orcd_column *col) {
+    col->index_loaded = true;
+    const orcd_stripe_footer *ft = col->footer;
+    if (col->column >= file->types.size() || col->column >= ft->columns.size()) return ORCD_OK;
+    const int type_kind = file->types[col->column].kind;
+    const int encoding = ft->columns[col->column].kind;
+    const orcd_stream_info *index = nullptr;
+    for (const auto &s : ft->streams)
+        if (s.column == col->column && s.kind == ORCD_STREAM_ROW_INDEX) index = &s;
+    if (!index || index->length == 0) return ORCD_OK;
+    // Each row-group entry lists the positions of the column's streams in stream-kind order
+    // (PRESENT, DATA, LENGTH, ... as in the ORC specification's per-type stream tables), which
+    // need not be the order of the streams inside the stripe.
+    struct Slot { uint32_t kind; int first; };
+    std::vector<Slot> slots;
+    int cursor = 0;
+    for (uint32_t kind = 0; kind < 8; kind++) {
+        if (kind == ORCD_STREAM_ROW_INDEX || kind == ORCD_STREAM_BLOOM_FILTER) continue;
+        bool present = false;
+        for (const auto &s : ft->streams) present = present || (s.column == col->column && s.kind == kind);
+        if (!present) continue;
+        const int n = positions_of(type_kind, encoding, kind);
+        if (n < 0) return ORCD_OK;  // a layout this reader does not know: no entry points
+        if (n > 0) slots.push_back({kind, cursor});
+        cursor += n;
+    }
+    std::vector<uint8_t> buf;
+    const orcd_stripe_info &si = file->stripes[col->stripe];
+    if (!file->src.read_at(si.offset + index->offset, index->length, buf)) return ORCD_OUT_OF_SPEC;
+    Cursor c{buf.data(), buf.data() + buf.size()};
+    uint32_t field, wire;
+    uint64_t v;
+    Cursor sub{nullptr, nullptr};
+    std::vector<uint64_t> pos;
+    while (c.next(field, wire, v, sub)) {
+        if (field != 1 || wire != 2) continue;  // RowIndexEntry
+        pos.clear();
+        uint32_t f2, w2;
+        uint64_t v2;
+        Cursor s2{nullptr, nullptr};
+        bool ok = true;
+        while (sub.next(f2, w2, v2, s2))
+            if (f2 == 1) read_repeated(w2, v2, s2, pos, ok);
+        if (!sub.ok || !ok) return ORCD_INVALID_PROTO;
+        if ((int)pos.size() != cursor) {  // unexpected shape: drop all entry points
+            for (auto &e : col->entries) e.clear();
+            return ORCD_OK;
+        }
+        for (const auto &sl : slots) {
+            std::vector<uint64_t> &e = col->entries[sl.kind];
+            const uint64_t off = pos[sl.first];
+            if (e.empty() || off > e.back()) e.push_back(off);  // ascending, no duplicates
+        }
+    }
+    if (!c.ok) return ORCD_INVALID_PROTO;
+    return ORCD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+static int open_common(orcd_file *f, orcd_file **out) {
+    const int rc = parse_tail(f);
+    if (rc != ORCD_OK) {
+        orcd_file_close(f);
+        return rc;
+    }
+    *out = f;
+    return ORCD_OK;
+}
+
+int orcd_file_open(const char *path, orcd_file **out) {
+    if (!path || !out) return ORCD_INVALID_ARGUMENT;
+    *out = nullptr;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return ORCD_OUT_OF_SPEC;  // io errors collapse to OutOfSpec (src/error.rs:29-33)
+    orcd_file *f = new orcd_file();
+    f->src.f = fp;
+    if (fseeko(fp, 0, SEEK_END) != 0) {
+        orcd_file_close(f);
+        return ORCD_OUT_OF_SPEC;
+    }
+    f->src.len = (uint64_t)ftello(fp);
+    return open_common(f, out);
+}
+
+int orcd_file_open_memory(const uint8_t *bytes, size_t len, orcd_file **out) {
+    if (!bytes || !out) return ORCD_INVALID_ARGUMENT;
+    *out = nullptr;
+    orcd_file *f = new orcd_file();
+    f->src.mem = bytes;
+    f->src.len = len;
+    return open_common(f, out);
+}
+
+void orcd_file_close(orcd_file *f) {
+    if (!f) return;
+    if (f->src.f) fclose(f->src.f);
+    delete f;
+}
+
+size_t orcd_file_num_stripes(const orcd_file *f) { return f ? f->stripes.size() : 0; }
+
+int orcd_file_stripe(const orcd_file *f, size_t stripe, orcd_stripe_info *info) {
+    if (!f || !info || stripe >= f->stripes.size()) return ORCD_INVALID_ARGUMENT;
+    *info = f->stripes[stripe];
+    return ORCD_OK;
+}
+
+int orcd_file_compression(const orcd_file *f) { return f ? f->compression : -1; }
+uint64_t orcd_file_number_of_rows(const orcd_file *f) { return f ? f->number_of_rows : 0; }
+uint32_t orcd_file_row_index_stride(const orcd_file *f) { return f ? f->row_index_stride : 0; }
+size_t orcd_file_num_types(const orcd_file *f) { return f ? f->types.size() : 0; }
+
+int orcd_file_type_kind(const orcd_file *f, size_t type_id) {
+    if (!f || type_id >= f->types.size()) return -1;
+    return f->types[type_id].kind;
+}
+
+int orcd_read_stripe_footer(orcd_file *f, size_t stripe, orcd_stripe_footer **out) {
+    if (!f || !out) return ORCD_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (stripe >= f->stripes.size()) return ORCD_INVALID_ARGUMENT;
+    const orcd_stripe_info &si = f->stripes[stripe];
+    std::vector<uint8_t> buf;
+    if (!f->src.read_at(si.offset + si.index_length + si.data_length, si.footer_length, buf))
+        return ORCD_OUT_OF_SPEC;
+    orcd_stripe_footer *ft = new orcd_stripe_footer();
+    ft->stripe = stripe;
+    const int rc = parse_stripe_footer(buf, ft);
+    if (rc != ORCD_OK) {
+        delete ft;
+        return rc;
+    }
+    *out = ft;
+    return ORCD_OK;
+}
+
+void orcd_stripe_footer_free(orcd_stripe_footer *ft) { delete ft; }
+
+size_t orcd_stripe_footer_num_streams(const orcd_stripe_footer *ft) { return ft ? ft->streams.size() : 0; }
+
+int orcd_stripe_footer_stream(const orcd_stripe_footer *ft, size_t i, orcd_stream_info *info) {
+    if (!ft || !info || i >= ft->streams.size()) return ORCD_INVALID_ARGUMENT;
+    *info = ft->streams[i];
+    return ORCD_OK;
+}
+
+int orcd_read_stripe_column(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft,
+                            uint32_t column, orcd_column **out) {
+    if (!f || !ft || !out) return ORCD_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (stripe >= f->stripes.size()) return ORCD_INVALID_ARGUMENT;
+    // first non-ROW_INDEX stream of the column and the total length of all of them
+    // (src/read/mod.rs:129-144)
+    bool found = false;
+    uint64_t start = 0, length = 0;
+    for (const auto &s : ft->streams) {
+        if (s.column != column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
+        if (!found) {
+            found = true;
+            start = s.offset;
+        }
+        length += s.length;
+    }
+    if (!found) return ORCD_INVALID_COLUMN;
+    orcd_column *col = new orcd_column();
+    if (!f->src.read_at(f->stripes[stripe].offset + start, length, col->data)) {
+        delete col;
+        return ORCD_OUT_OF_SPEC;
+    }
+    col->column = column;
+    col->number_of_rows = f->stripes[stripe].number_of_rows;
+    col->stripe = stripe;
+    col->footer = ft;
+    *out = col;
+    return ORCD_OK;
+}
+
+void orcd_column_free(orcd_column *col) { delete col; }
+
+int orcd_column_get_stream(const orcd_column *col, int kind, const uint8_t **bytes, size_t *len) {
+    if (!col || !bytes || !len) return ORCD_INVALID_ARGUMENT;
+    // running offset over the column's non-ROW_INDEX streams (src/read/column.rs:38-55)
+    uint64_t start = 0;
+    for (const auto &s : col->footer->streams) {
+        if (s.column != col->column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
+        if ((int)s.kind == kind) {
+            if (start + s.length > col->data.size()) return ORCD_OUT_OF_SPEC;
+            *bytes = col->data.data() + start;
+            *len = (size_t)s.length;
+            return ORCD_OK;
+        }
+        start += s.length;
+    }
+    return ORCD_INVALID_KIND;
+}
+
+int orcd_column_encoding(const orcd_column *col, int *kind, uint32_t *dictionary_size) {
+    if (!col || col->column >= col->footer->columns.size()) return ORCD_INVALID_COLUMN;
+    const Encoding &e = col->footer->columns[col->column];
+    if (kind) *kind = e.kind;
+    if (dictionary_size) *dictionary_size = e.has_dict ? e.dictionary_size : 0;
+    return ORCD_OK;
+}
+
+uint64_t orcd_column_number_of_rows(const orcd_column *col) { return col ? col->number_of_rows : 0; }
+
+int orcd_column_entry_points(orcd_file *f, orcd_column *col, int kind, const uint64_t **entries,
+                             size_t *n_entries) {
+    if (!f || !col || !entries || !n_entries || kind < 0 || kind >= 8) return ORCD_INVALID_ARGUMENT;
+    if (!col->index_loaded) {
+        const int rc = load_entry_points(f, col);
+        if (rc != ORCD_OK) return rc;
+    }
+    *entries = col->entries[kind].data();
+    *n_entries = col->entries[kind].size();
+    return ORCD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// Shared declarations of the decoder's translation units (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orcd.h"
+
+namespace orcd {
+
+// ---- RLE v2 run table -------------------------------------------------------------------------
+// Written by the header-scan kernel, read by the value kernel: everything the value kernel needs
+// is here, so it never parses a header.
+//
+// desc bit layout
+//   [0,40)  payload_off   offset in the stream of the run's packed bytes
+//   [40,42) kind          0 ShortRepeat, 1 Direct, 2 PatchedBase, 3 Delta
+//   [42,49) width         packed bit width, 0..64
+//   [49,58) len - 1       run length 1..512
+//   58      delta_neg     Delta: the per-value deltas are subtracted
+struct RunEntry {
+    uint64_t desc;
+    uint64_t out_off;  // index of the run's first value in the output
+    uint64_t base;     // ShortRepeat: the value (zigzag applied for signed streams);
+                       // Delta: first value; PatchedBase: base
+    uint64_t aux;      // Delta: signed delta_base; PatchedBase: patch geometry (see PB_* below)
+};
+static_assert(sizeof(RunEntry) == 32, "RunEntry is read as two 16-byte loads");
+
+constexpr int KIND_SHORT_REPEAT = 0, KIND_DIRECT = 1, KIND_PATCHED_BASE = 2, KIND_DELTA = 3;
+constexpr uint64_t PAYLOAD_MASK = (1ull << 40) - 1;
+
+__host__ __device__ inline uint64_t make_desc(uint64_t payload_off, uint32_t kind, uint32_t width,
+                                              uint32_t len, uint32_t delta_neg) {
+    return (payload_off & PAYLOAD_MASK) | ((uint64_t)kind << 40) | ((uint64_t)width << 42) |
+           ((uint64_t)(len - 1) << 49) | ((uint64_t)delta_neg << 58);
+}
+__host__ __device__ inline uint64_t desc_payload(uint64_t d) { return d & PAYLOAD_MASK; }
+__host__ __device__ inline uint32_t desc_kind(uint64_t d) { return (uint32_t)(d >> 40) & 3u; }
+__host__ __device__ inline uint32_t desc_width(uint64_t d) { return (uint32_t)(d >> 42) & 127u; }
+__host__ __device__ inline uint32_t desc_len(uint64_t d) { return ((uint32_t)(d >> 49) & 511u) + 1u; }
+__host__ __device__ inline uint32_t desc_delta_neg(uint64_t d) { return (uint32_t)(d >> 58) & 1u; }
+
+// PatchedBase geometry packed in RunEntry::aux:
+//   [0,7) patch width  [7,11) gap width  [11,16) patch list length  [16,23) packed entry width
+__host__ __device__ inline uint64_t make_pb_aux(uint32_t pw, uint32_t gw, uint32_t pll, uint32_t cfb) {
+    return (uint64_t)pw | ((uint64_t)gw << 7) | ((uint64_t)pll << 11) | ((uint64_t)cfb << 16);
+}
+__host__ __device__ inline uint32_t pb_patch_width(uint64_t a) { return (uint32_t)a & 127u; }
+__host__ __device__ inline uint32_t pb_gap_width(uint64_t a) { return (uint32_t)(a >> 7) & 15u; }
+__host__ __device__ inline uint32_t pb_list_len(uint64_t a) { return (uint32_t)(a >> 11) & 31u; }
+__host__ __device__ inline uint32_t pb_entry_bits(uint64_t a) { return (uint32_t)(a >> 16) & 127u; }
+
+// Per-segment result of the counting pass (a segment = the headers between two entry points).
+struct SegCount {
+    uint32_t n_runs;
+    uint32_t last_len;  // length of the segment's last run
+    uint32_t status;    // SEG_*
+    uint32_t pad;
+    uint64_t n_vals;
+};
+// Per-segment offsets produced by the segment scan.
+struct SegOffset {
+    uint64_t val_off;   // values before this segment
+    uint32_t run_off;   // runs before this segment
+    uint32_t prev_len;  // length of the last run before this segment (0: none)
+};
+// Totals of one stream, read back by the host after the segment scan.
+struct ScanTotals {
+    uint64_t total_vals;
+    uint64_t total_runs;
+    uint32_t error;      // ORCD_* status; 0 when the first `num_values` values are decodable
+    uint32_t error_seg;
+    uint64_t pad;
+};
+
+constexpr uint32_t SEG_OK = 0;
+constexpr uint32_t SEG_TRUNCATED = 1;    // a run extends past the end of the stream
+constexpr uint32_t SEG_MISALIGNED = 2;   // the walk stepped over the next entry point
+constexpr uint32_t SEG_BAD_RUN = 3;      // a header that the specification forbids
+constexpr uint32_t SEG_TOO_LONG = 4;     // stream offset does not fit the run table
+
+// Values per output window: one wavefront decodes an aligned window of 512 values (8 per lane).
+constexpr uint32_t WINDOW_SHIFT = 9;
+constexpr uint32_t WINDOW = 1u << WINDOW_SHIFT;
+
+// ---- byte-RLE run table -------------------------------------------------------------------------
+// src: [0,40) offset of the value byte (run) or of the first literal byte, [40,48) len-1, bit 48 is_run
+struct ByteRun {
+    uint64_t src;
+    uint64_t out_off;
+};
+
+// ---- launchers (defined in the .hip files, called from the C ABI layer) ---------------------
+struct Rlev2Plan {       // device pointers into the context arena
+    SegCount *seg_count;
+    SegOffset *seg_off;
+    ScanTotals *totals;
+    RunEntry *runs;
+    uint32_t *group_first;
+};
+
+hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t len,
+                              const uint64_t *entries, uint32_t n_seg, int is_signed,
+                              SegCount *seg_count);
+hipError_t launch_segment_scan(hipStream_t st, const SegCount *seg_count, uint32_t n_seg,
+                               uint64_t num_values, SegOffset *seg_off, ScanTotals *totals);
+hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
+                             const uint64_t *entries, uint32_t n_seg, int is_signed,
+                             const SegCount *seg_count, const SegOffset *seg_off, RunEntry *runs,
+                             uint32_t *group_first, uint32_t n_group_slots);
+hipError_t launch_rlev2_values(hipStream_t st, const uint8_t *stream, uint64_t len,
+                               const RunEntry *runs, const uint32_t *group_first,
+                               uint32_t n_groups, uint64_t num_values, int is_signed,
+                               int64_t *out);
+
+hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                 const uint64_t *entries, uint32_t n_seg, SegCount *seg_count);
+hipError_t launch_byte_rle_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                const uint64_t *entries, uint32_t n_seg, const SegCount *seg_count,
+                                const SegOffset *seg_off, ByteRun *runs);
+hipError_t launch_byte_rle_expand(hipStream_t st, const uint8_t *stream, const ByteRun *runs,
+                                  uint64_t n_runs, uint64_t num_bytes, uint8_t *out);
+hipError_t launch_bool_expand(hipStream_t st, const uint8_t *packed, uint64_t num_bits,
+                              uint8_t *out_bytes, uint8_t *out_bitmap, uint64_t *set_bits);
+
+// In-place exclusive prefix sum of n 64-bit values; data[n] receives the total.
+// `block_sums` needs room for scan_block_sums_len(n) values.
+size_t scan_block_sums_len(uint64_t n);
+hipError_t launch_exclusive_scan_u64(hipStream_t st, uint64_t *data, uint64_t n,
+                                     uint64_t *block_sums);
+
+hipError_t launch_utf8_validate(hipStream_t st, const uint8_t *bytes, const int64_t *offsets,
+                                uint64_t n, uint32_t *invalid_flag, uint64_t total_bytes);
+hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
+                                     const int64_t *indices, uint64_t n, uint64_t *lengths_out,
+                                     uint32_t *error_flag);
+hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
+                                    const uint8_t *dict_bytes, const int64_t *indices, uint64_t n,
+                                    const int64_t *offsets_out, uint8_t *bytes_out);
+
+}  // namespace orcd

@@ -98,10 +98,13 @@ def main():
             "bools": bools, "strs": strs,
         })
         # 'compression' strategy turns off aligned bit packing -> widths such as 17 and 10
+        # one large stripe with a row-group index entry every 1000 rows ...
         _write(mixed, "mixed_compression.orc", compression_strategy="compression",
-               dictionary_key_size_threshold=0.0, stripe_size=256 * 1024, row_index_stride=5000)
+               dictionary_key_size_threshold=0.0, stripe_size=8 * 1024 * 1024,
+               row_index_stride=1000, batch_size=20000)
+        # ... and many small stripes
         _write(mixed, "mixed_speed.orc", compression_strategy="speed",
-               dictionary_key_size_threshold=0.0, stripe_size=256 * 1024, row_index_stride=5000)
+               dictionary_key_size_threshold=0.0, stripe_size=256 * 1024, row_index_stride=1000)
 
     expected = {
         # tests/it/main.rs:26-176, 298-316

@@ -47,7 +47,7 @@ class Oracle:
 
     def runs(self, stream, n):
         s = _u8(stream)
-        cap = max(16, n)
+        cap = max(16, min(n, s.size))  # a run takes at least two stream bytes
         arr = (Run * cap)()
         cnt = C.c_size_t(0)
         rc = self.lib.orc_oracle_rlev2_runs(s.ctypes.data, s.size, n, arr, cap, C.byref(cnt))

@@ -1,0 +1,145 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports what include/orcd.h
+declares, and the C++ host reader (file tail, stripe footers, column regions, ROW_INDEX entry
+points) agrees with an independent pure-Python parse of the same fixture files."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc_pyparse as op
+from orc_format_amd import _native as N
+from orc_format_amd import read
+from orc_format_amd.error import OrcError
+from orc_format_amd.proto import ColumnEncodingKind, StreamKind
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURES = ["test.orc", "long_bool.orc", "string_long.orc", "string_dict.orc",
+            "string_long_long.orc", "mixed_compression.orc", "mixed_speed.orc"]
+
+
+def test_library_exports_every_declared_symbol():
+    with open(os.path.join(ROOT, "include", "orcd.h")) as f:
+        header = f.read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(orcd_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    lib = N.lib()
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, missing
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+
+
+def test_strerror():
+    assert N.lib().orcd_strerror(1) == b"out of spec"
+    assert N.lib().orcd_strerror(0) == b"ok"
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_metadata_matches_python_parse(golden_dir, name):
+    path = os.path.join(golden_dir, name)
+    ref = op.OrcFile(path)
+    md = read.read_metadata(path)
+    assert md.compression == 0
+    assert md.number_of_rows == ref.number_of_rows
+    assert md.row_index_stride == ref.row_index_stride
+    assert md.types == [t[0] for t in ref.types]
+    got = [(s.offset, s.index_length, s.data_length, s.footer_length, s.number_of_rows)
+           for s in md.stripes]
+    assert got == [tuple(s) for s in ref.stripes]
+    for si in range(len(ref.stripes)):
+        footer = read.read_stripe_footer(md, si)
+        rstreams, rencodings = ref.stripe_footer(si)
+        assert [(s.kind, s.column, s.length, s.offset + ref.stripes[si].offset)
+                for s in footer.streams] == [tuple(s) for s in rstreams]
+        for col in range(1, len(ref.types)):
+            column = read.read_stripe_column(md, si, footer, col)
+            assert column.number_of_rows() == ref.stripes[si].number_of_rows
+            assert int(column.encoding()) == rencodings[col][0]
+            for kind in (StreamKind.Present, StreamKind.Data, StreamKind.Length,
+                         StreamKind.DictionaryData):
+                expect = ref.stream(si, col, int(kind))
+                if expect is None:
+                    assert not column.has_stream(kind)
+                    with pytest.raises(OrcError) as e:
+                        column.get_stream(kind)
+                    assert e.value.variant == "InvalidKind"
+                else:
+                    assert bytes(column.get_stream(kind)) == expect
+
+
+def test_memory_image_and_dictionary_size(golden_dir):
+    with open(os.path.join(golden_dir, "string_dict.orc"), "rb") as f:
+        image = f.read()
+    md = read.read_metadata(image)
+    footer = read.read_stripe_footer(md, 0)
+    column = read.read_stripe_column(md, 0, footer, 1)
+    assert column.encoding() == ColumnEncodingKind.DictionaryV2
+    assert column.dictionary_size() == 2
+    assert bytes(column.get_stream(StreamKind.DictionaryData)) == b"abcefgh"
+
+
+def test_invalid_column_and_bad_files(golden_dir, tmp_path):
+    md = read.read_metadata(os.path.join(golden_dir, "test.orc"))
+    footer = read.read_stripe_footer(md, 0)
+    with pytest.raises(OrcError) as e:
+        read.read_stripe_column(md, 0, footer, 99)
+    assert e.value.variant == "InvalidColumn"
+    with pytest.raises(OrcError):
+        read.read_metadata(str(tmp_path / "missing.orc"))
+    with open(os.path.join(golden_dir, "test.orc"), "rb") as f:
+        image = f.read()
+    # a tail cut in the middle of the footer must be an error, not a crash
+    for cut in (1, 2, 3, len(image) // 2):
+        with pytest.raises(OrcError):
+            read.read_metadata(b"ORC" + image[3:cut + 3] if cut < 4 else b"ORC" + image[-cut:-1])
+
+
+def test_large_tail_is_reread(tmp_path):
+    """A footer beyond the 16 KiB the reference reads (src/read/mod.rs:22,53-82)."""
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    cols = {("c%03d_" % i) + "x" * 60: pa.array([i, i + 1, i + 2], type=pa.int64())
+            for i in range(400)}
+    path = str(tmp_path / "wide.orc")
+    orc.write_table(pa.table(cols), path, compression="uncompressed")
+    ref = op.OrcFile(path)
+    assert ref.footer_length + ref.metadata_length > 16 * 1024
+    md = read.read_metadata(path)
+    assert len(md.types) == 401 and md.number_of_rows == 3
+
+
+@pytest.mark.parametrize("name", ["mixed_compression.orc", "mixed_speed.orc"])
+def test_entry_points_are_run_starts(oracle, golden_dir, name):
+    path = os.path.join(golden_dir, name)
+    ref = op.OrcFile(path)
+    md = read.read_metadata(path)
+    checked = 0
+    for si in range(len(ref.stripes)):
+        footer = read.read_stripe_footer(md, si)
+        for col in range(1, len(ref.types)):
+            kind = ref.types[col][0]
+            column = read.read_stripe_column(md, si, footer, col)
+            if kind in (2, 3, 4):  # RLE v2 DATA
+                stream = ref.stream(si, col, op.DATA)
+                entries = column.entry_points(StreamKind.Data)
+                rc, runs = oracle.runs(stream, 10**9)  # walks to the end of the stream
+                starts = {r[3] for r in runs}
+                assert len(entries) >= 1 and set(entries.tolist()) <= starts, (si, col)
+                checked += len(entries)
+            if kind == 7:
+                stream = ref.stream(si, col, op.LENGTH)
+                entries = column.entry_points(StreamKind.Length)
+                rc, runs = oracle.runs(stream, 10**9)
+                assert set(entries.tolist()) <= {r[3] for r in runs}
+            if ref.stream(si, col, op.PRESENT) is not None:
+                entries = column.entry_points(StreamKind.Present)
+                stream = ref.stream(si, col, op.PRESENT)
+                # control-byte offsets of the byte-RLE stream
+                pos, starts = 0, set()
+                while pos < len(stream):
+                    starts.add(pos)
+                    c = stream[pos]
+                    pos += 2 if c < 128 else 1 + 256 - c
+                assert set(entries.tolist()) <= starts, (si, col)
+    assert checked > 8
