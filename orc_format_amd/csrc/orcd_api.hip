@@ -176,7 +176,7 @@ int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_va
     Rlev2Table t;
     ORCD_TRY(rlev2_table(c, d_stream, len, num_values, d_entries, n_entries, is_signed, &t));
     HIP_TRY(c, launch_rlev2_values(c->stream, d_stream, len, t.runs, t.group_first, t.n_groups,
-                                   num_values, is_signed, d_out));
+                                   (uint32_t)t.total_runs, num_values, is_signed, d_out));
     mark(c, 3);
     return ORCD_OK;
 }

@@ -111,8 +111,8 @@ hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len
                              uint32_t *group_first, uint32_t n_group_slots);
 hipError_t launch_rlev2_values(hipStream_t st, const uint8_t *stream, uint64_t len,
                                const RunEntry *runs, const uint32_t *group_first,
-                               uint32_t n_groups, uint64_t num_values, int is_signed,
-                               int64_t *out);
+                               uint32_t n_groups, uint32_t n_runs, uint64_t num_values,
+                               int is_signed, int64_t *out);
 
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                                  const uint64_t *entries, uint32_t n_seg, SegCount *seg_count);

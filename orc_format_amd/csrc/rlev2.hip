@@ -232,8 +232,12 @@ __global__ __launch_bounds__(256) void rlev2_scan_kernel(
             e.base = 0;
             e.aux = 0;
             runs[run_idx] = e;
-            const uint64_t g = (out_off + WINDOW - 1) >> WINDOW_SHIFT;
-            if (g < n_group_slots) group_first[g] = run_idx;
+            // Windows in which no run starts exist only at the tail: the last run may reach
+            // into one more window.  They, and the slot one past the last window, get the
+            // sentinel's index (an empty group).
+            const uint64_t g_end = (out_off + WINDOW - 1) >> WINDOW_SHIFT;
+            uint64_t g = out_off == 0 ? 0 : ((out_off - prev_len) >> WINDOW_SHIFT) + 1;
+            for (; g <= g_end && g < n_group_slots; g++) group_first[g] = run_idx;
         }
     }
 }
@@ -368,8 +372,8 @@ struct RunFields {
 
 __global__ __launch_bounds__(VAL_WAVES * 64) void rlev2_values_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const RunEntry *__restrict__ runs,
-    const uint32_t *__restrict__ group_first, uint32_t n_groups, uint64_t num_values,
-    int is_signed, int64_t *__restrict__ out) {
+    const uint32_t *__restrict__ group_first, uint32_t n_groups, uint32_t n_runs,
+    uint64_t num_values, int is_signed, int64_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[VAL_WAVES][STAGE_WORDS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -378,8 +382,11 @@ __global__ __launch_bounds__(VAL_WAVES * 64) void rlev2_values_kernel(
     uint32_t *lds = stage[wave];
     const bool out_aligned = (((uintptr_t)out) & 15) == 0;
 
-    const uint32_t r0 = __builtin_amdgcn_readfirstlane(group_first[g]);
-    const uint32_t r1 = __builtin_amdgcn_readfirstlane(group_first[g + 1]);
+    // the group's runs; clamped to the table so that a bad index can never walk off it
+    uint32_t r1 = __builtin_amdgcn_readfirstlane(group_first[g + 1]);
+    if (r1 > n_runs) r1 = n_runs;
+    uint32_t r0 = __builtin_amdgcn_readfirstlane(group_first[g]);
+    if (r0 > r1) r0 = r1;
 
     for (uint32_t rb = r0; rb < r1; rb += 64) {
         const uint32_t nb = (r1 - rb) < 64u ? (r1 - rb) : 64u;
@@ -609,12 +616,12 @@ hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len
 
 hipError_t launch_rlev2_values(hipStream_t st, const uint8_t *stream, uint64_t len,
                                const RunEntry *runs, const uint32_t *group_first,
-                               uint32_t n_groups, uint64_t num_values, int is_signed,
-                               int64_t *out) {
+                               uint32_t n_groups, uint32_t n_runs, uint64_t num_values,
+                               int is_signed, int64_t *out) {
     if (n_groups == 0) return hipSuccess;
     const uint32_t blocks = (n_groups + VAL_WAVES - 1) / VAL_WAVES;
-    rlev2_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, runs, group_first,
-                                                          n_groups, num_values, is_signed, out);
+    rlev2_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, runs, group_first, n_groups,
+                                                          n_runs, num_values, is_signed, out);
     return hipGetLastError();
 }
 
