@@ -6,20 +6,21 @@
 // literal lengths are exactly those of the ORC specification.  Same two-phase shape as the RLE v2
 // decoder: control bytes form a serial chain walked per segment, then the bytes are expanded.
 #include "orcd_internal.h"
+#include "seg_scan.h"
 
 namespace orcd {
 
 constexpr uint64_t BR_IS_RUN = 1ull << 48;
 
 template <bool EMIT>
-__global__ __launch_bounds__(256) void byte_rle_scan_kernel(
+__global__ __launch_bounds__(SEG_BLOCK) void byte_rle_scan_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
-    uint32_t n_seg, SegCount *__restrict__ seg_count, const SegOffset *__restrict__ seg_off,
-    ByteRun *__restrict__ runs) {
-    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seg >= n_seg) return;
-    uint64_t pos = (entries && seg > 0) ? entries[seg] : 0;
-    const uint64_t end = (entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
+    uint32_t n_seg, SegTable t, ByteRun *__restrict__ runs) {
+    const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
+    const bool valid = seg < n_seg;
+    if (EMIT && !valid) return;
+    uint64_t pos = (valid && entries && seg > 0) ? entries[seg] : 0;
+    const uint64_t end = (valid && entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
     const bool last_seg = seg + 1 == n_seg;
     if (pos > len) pos = len;
     uint32_t n_runs = 0, status = SEG_OK, last_len = 0;
@@ -27,13 +28,14 @@ __global__ __launch_bounds__(256) void byte_rle_scan_kernel(
     uint64_t out_off = 0;
     uint32_t run_idx = 0, want_runs = 0xFFFFFFFFu;
     if (EMIT) {
-        out_off = seg_off[seg].val_off;
-        run_idx = seg_off[seg].run_off;
-        want_runs = seg_count[seg].n_runs;
+        const SegOffset so = seg_global_offset(t, seg);
+        out_off = so.val_off;
+        run_idx = so.run_off;
+        want_runs = t.seg_count[seg].n_runs;
     } else if (end > len || end < pos) {
         status = SEG_MISALIGNED;
     }
-    while (status == SEG_OK && pos < end && n_runs < want_runs) {
+    while (valid && status == SEG_OK && pos < end && n_runs < want_runs) {
         const uint32_t c = s[pos];
         uint32_t n;
         uint64_t next;
@@ -63,13 +65,7 @@ __global__ __launch_bounds__(256) void byte_rle_scan_kernel(
     }
     if (!EMIT) {
         if (status == SEG_OK && pos != end && !last_seg) status = SEG_MISALIGNED;
-        SegCount c;
-        c.n_runs = n_runs;
-        c.last_len = last_len;
-        c.status = status;
-        c.pad = 0;
-        c.n_vals = n_bytes;
-        seg_count[seg] = c;
+        seg_publish(t, seg, n_seg, n_runs, last_len, status, n_bytes);
     }
 }
 
@@ -130,17 +126,17 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(const uint8_t *__restr
 }
 
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                 const uint64_t *entries, uint32_t n_seg, SegCount *seg_count) {
-    byte_rle_scan_kernel<false><<<(n_seg + 255) / 256, 256, 0, st>>>(stream, len, entries, n_seg,
-                                                                    seg_count, nullptr, nullptr);
+                                 const uint64_t *entries, uint32_t n_seg, const SegTable &t) {
+    byte_rle_scan_kernel<false><<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(
+        stream, len, entries, n_seg, t, nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_byte_rle_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                const uint64_t *entries, uint32_t n_seg, const SegCount *seg_count,
-                                const SegOffset *seg_off, ByteRun *runs) {
-    byte_rle_scan_kernel<true><<<(n_seg + 255) / 256, 256, 0, st>>>(
-        stream, len, entries, n_seg, const_cast<SegCount *>(seg_count), seg_off, runs);
+                                const uint64_t *entries, uint32_t n_seg, const SegTable &t,
+                                ByteRun *runs) {
+    byte_rle_scan_kernel<true><<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(
+        stream, len, entries, n_seg, t, runs);
     return hipGetLastError();
 }
 

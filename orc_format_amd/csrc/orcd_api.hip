@@ -6,6 +6,7 @@
 #include <algorithm>
 
 #include "orcd_internal.h"
+#include "seg_scan.h"
 
 using namespace orcd;
 
@@ -19,9 +20,12 @@ enum Slot {
     SLOT_IN_D,
     SLOT_SEG_COUNT,
     SLOT_SEG_OFF,
+    SLOT_BLK_TOTALS,
+    SLOT_BLK_OFF,
     SLOT_TOTALS,
     SLOT_RUNS,
     SLOT_GROUPS,
+    SLOT_GROUP_RUNS,
     SLOT_OUT_A,        // device staging of a host output
     SLOT_OUT_B,
     SLOT_PACKED,       // byte-RLE output feeding the boolean expansion
@@ -107,26 +111,31 @@ void reset_events(orcd_ctx *c) {
 }
 
 struct ScanResult {
-    const SegCount *seg_count;
-    const SegOffset *seg_off;
+    SegTable table;
     ScanTotals totals;
 };
 
-// Header count + segment prefix sums + read-back of the totals (the one host sync of a decode).
+// Header count + prefix sums + read-back of the totals (the one host sync of a decode).
 template <typename CountFn>
 int count_and_scan(orcd_ctx *c, uint32_t n_seg, uint64_t num_values, CountFn count, ScanResult *res) {
-    void *seg_count, *seg_off, *totals;
+    const uint32_t n_blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
+    void *seg_count, *seg_off, *blk, *boff, *totals;
     ORCD_TRY(ensure(c, SLOT_SEG_COUNT, (size_t)n_seg * sizeof(SegCount), &seg_count));
     ORCD_TRY(ensure(c, SLOT_SEG_OFF, (size_t)n_seg * sizeof(SegOffset), &seg_off));
+    ORCD_TRY(ensure(c, SLOT_BLK_TOTALS, (size_t)n_blocks * sizeof(BlockTotals), &blk));
+    ORCD_TRY(ensure(c, SLOT_BLK_OFF, (size_t)n_blocks * sizeof(BlockOffset), &boff));
     ORCD_TRY(ensure(c, SLOT_TOTALS, sizeof(ScanTotals), &totals));
-    HIP_TRY(c, count((SegCount *)seg_count));
-    HIP_TRY(c, launch_segment_scan(c->stream, (const SegCount *)seg_count, n_seg, num_values,
-                                   (SegOffset *)seg_off, (ScanTotals *)totals));
+    SegTable &t = res->table;
+    t.seg_count = (SegCount *)seg_count;
+    t.seg_local = (SegOffset *)seg_off;
+    t.blk = (BlockTotals *)blk;
+    t.boff = (BlockOffset *)boff;
+    t.totals = (ScanTotals *)totals;
+    HIP_TRY(c, count(t));
+    HIP_TRY(c, launch_block_totals_scan(c->stream, t, n_blocks, num_values));
     HIP_TRY(c, hipMemcpyAsync(c->h_totals, totals, sizeof(ScanTotals), hipMemcpyDeviceToHost,
                               c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    res->seg_count = (const SegCount *)seg_count;
-    res->seg_off = (const SegOffset *)seg_off;
     res->totals = *c->h_totals;
     return ORCD_OK;
 }
@@ -136,6 +145,7 @@ uint32_t segments_for(size_t n_entries) { return n_entries ? (uint32_t)n_entries
 struct Rlev2Table {
     const RunEntry *runs;
     const uint32_t *group_first;
+    const RunEntry *group_run;
     uint32_t n_groups;
     uint64_t total_runs;
 };
@@ -147,24 +157,26 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
     ScanResult sr;
-    ORCD_TRY(count_and_scan(c, n_seg, num_values, [&](SegCount *sc) {
-        return launch_rlev2_count(c->stream, d_stream, len, entries, n_seg, is_signed, sc);
+    ORCD_TRY(count_and_scan(c, n_seg, num_values, [&](const SegTable &t) {
+        return launch_rlev2_count(c->stream, d_stream, len, entries, n_seg, is_signed, t);
     }, &sr));
     mark(c, 1);
     if (sr.totals.error) return (int)sr.totals.error;
     if (sr.totals.total_runs >= 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
     const uint64_t n_slots = ((sr.totals.total_vals + WINDOW - 1) >> WINDOW_SHIFT) + 1;
     if (n_slots > 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
-    void *runs, *groups;
+    void *runs, *groups, *group_runs;
     ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(RunEntry), &runs));
     ORCD_TRY(ensure(c, SLOT_GROUPS, (size_t)n_slots * sizeof(uint32_t), &groups));
-    HIP_TRY(c, launch_rlev2_emit(c->stream, d_stream, len, entries, n_seg, is_signed, sr.seg_count,
-                                 sr.seg_off, (RunEntry *)runs, (uint32_t *)groups,
+    ORCD_TRY(ensure(c, SLOT_GROUP_RUNS, (size_t)n_slots * sizeof(RunEntry), &group_runs));
+    HIP_TRY(c, launch_rlev2_emit(c->stream, d_stream, len, entries, n_seg, is_signed, sr.table,
+                                 (RunEntry *)runs, (uint32_t *)groups, (RunEntry *)group_runs,
                                  (uint32_t)n_slots));
     mark(c, 2);
     const uint64_t covered = std::min<uint64_t>(num_values, sr.totals.total_vals);
     t->runs = (const RunEntry *)runs;
     t->group_first = (const uint32_t *)groups;
+    t->group_run = (const RunEntry *)group_runs;
     t->n_groups = (uint32_t)((covered + WINDOW - 1) >> WINDOW_SHIFT);
     t->total_runs = sr.totals.total_runs;
     return ORCD_OK;
@@ -175,8 +187,9 @@ int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_va
                  const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out) {
     Rlev2Table t;
     ORCD_TRY(rlev2_table(c, d_stream, len, num_values, d_entries, n_entries, is_signed, &t));
-    HIP_TRY(c, launch_rlev2_values(c->stream, d_stream, len, t.runs, t.group_first, t.n_groups,
-                                   (uint32_t)t.total_runs, num_values, is_signed, d_out));
+    HIP_TRY(c, launch_rlev2_values(c->stream, d_stream, len, t.runs, t.group_first, t.group_run,
+                                   t.n_groups, (uint32_t)t.total_runs, num_values, is_signed,
+                                   d_out));
     mark(c, 3);
     return ORCD_OK;
 }
@@ -188,16 +201,16 @@ int byte_rle_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
     ScanResult sr;
-    ORCD_TRY(count_and_scan(c, n_seg, num_bytes, [&](SegCount *sc) {
-        return launch_byte_rle_count(c->stream, d_stream, len, entries, n_seg, sc);
+    ORCD_TRY(count_and_scan(c, n_seg, num_bytes, [&](const SegTable &t) {
+        return launch_byte_rle_count(c->stream, d_stream, len, entries, n_seg, t);
     }, &sr));
     mark(c, 1);
     if (sr.totals.error) return (int)sr.totals.error;
     if (sr.totals.total_runs >= 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
     void *runs;
     ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(ByteRun), &runs));
-    HIP_TRY(c, launch_byte_rle_emit(c->stream, d_stream, len, entries, n_seg, sr.seg_count,
-                                    sr.seg_off, (ByteRun *)runs));
+    HIP_TRY(c, launch_byte_rle_emit(c->stream, d_stream, len, entries, n_seg, sr.table,
+                                    (ByteRun *)runs));
     mark(c, 2);
     HIP_TRY(c, launch_byte_rle_expand(c->stream, d_stream, (const ByteRun *)runs,
                                       sr.totals.total_runs, num_bytes, d_out));

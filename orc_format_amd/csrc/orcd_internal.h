@@ -18,6 +18,7 @@ namespace orcd {
 //   [42,49) width         packed bit width, 0..64
 //   [49,58) len - 1       run length 1..512
 //   58      delta_neg     Delta: the per-value deltas are subtracted
+//   59      single        (per-window copies only) no other run starts in the window
 struct RunEntry {
     uint64_t desc;
     uint64_t out_off;  // index of the run's first value in the output
@@ -29,6 +30,7 @@ static_assert(sizeof(RunEntry) == 32, "RunEntry is read as two 16-byte loads");
 
 constexpr int KIND_SHORT_REPEAT = 0, KIND_DIRECT = 1, KIND_PATCHED_BASE = 2, KIND_DELTA = 3;
 constexpr uint64_t PAYLOAD_MASK = (1ull << 40) - 1;
+constexpr uint64_t DESC_SINGLE = 1ull << 59;
 
 __host__ __device__ inline uint64_t make_desc(uint64_t payload_off, uint32_t kind, uint32_t width,
                                               uint32_t len, uint32_t delta_neg) {
@@ -92,33 +94,25 @@ struct ByteRun {
 };
 
 // ---- launchers (defined in the .hip files, called from the C ABI layer) ---------------------
-struct Rlev2Plan {       // device pointers into the context arena
-    SegCount *seg_count;
-    SegOffset *seg_off;
-    ScanTotals *totals;
-    RunEntry *runs;
-    uint32_t *group_first;
-};
+struct SegTable;  // seg_scan.h
 
 hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                               const uint64_t *entries, uint32_t n_seg, int is_signed,
-                              SegCount *seg_count);
-hipError_t launch_segment_scan(hipStream_t st, const SegCount *seg_count, uint32_t n_seg,
-                               uint64_t num_values, SegOffset *seg_off, ScanTotals *totals);
+                              const SegTable &t);
 hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                              const uint64_t *entries, uint32_t n_seg, int is_signed,
-                             const SegCount *seg_count, const SegOffset *seg_off, RunEntry *runs,
-                             uint32_t *group_first, uint32_t n_group_slots);
+                             const SegTable &t, RunEntry *runs, uint32_t *group_first,
+                             RunEntry *group_run, uint32_t n_group_slots);
 hipError_t launch_rlev2_values(hipStream_t st, const uint8_t *stream, uint64_t len,
                                const RunEntry *runs, const uint32_t *group_first,
-                               uint32_t n_groups, uint32_t n_runs, uint64_t num_values,
-                               int is_signed, int64_t *out);
+                               const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
+                               uint64_t num_values, int is_signed, int64_t *out);
 
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                 const uint64_t *entries, uint32_t n_seg, SegCount *seg_count);
+                                 const uint64_t *entries, uint32_t n_seg, const SegTable &t);
 hipError_t launch_byte_rle_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                const uint64_t *entries, uint32_t n_seg, const SegCount *seg_count,
-                                const SegOffset *seg_off, ByteRun *runs);
+                                const uint64_t *entries, uint32_t n_seg, const SegTable &t,
+                                ByteRun *runs);
 hipError_t launch_byte_rle_expand(hipStream_t st, const uint8_t *stream, const ByteRun *runs,
                                   uint64_t n_runs, uint64_t num_bytes, uint8_t *out);
 hipError_t launch_bool_expand(hipStream_t st, const uint8_t *packed, uint64_t num_bits,

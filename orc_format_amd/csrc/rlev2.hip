@@ -7,6 +7,7 @@
 // between two caller-supplied entry points) by one lane each, and the values -- the bulk of the
 // bytes -- are then expanded by one wavefront per aligned window of 512 output values.
 #include "orcd_internal.h"
+#include "seg_scan.h"
 
 namespace orcd {
 
@@ -42,6 +43,11 @@ __device__ __forceinline__ uint64_t shfl_up64(uint64_t v, unsigned d) {
 __device__ __forceinline__ uint32_t readlane32(uint32_t v, int lane) {
     return __builtin_amdgcn_readlane(v, lane);
 }
+__device__ __forceinline__ uint64_t readfirstlane64(uint64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
     uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane);
     uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), lane);
@@ -68,9 +74,11 @@ __device__ __forceinline__ Window16 load_window(const uint8_t *s, uint64_t len, 
     const uintptr_t end = (uintptr_t)(s + len);
     const uint32_t sh = (uint32_t)(a & 7) * 8;
     const uint64_t *p = (const uint64_t *)a0;
+    // all three loads are issued together: a word past the end is replaced by a re-read of the
+    // first word (select on the address, not on the load)
     const uint64_t q0 = p[0];
-    const uint64_t q1 = (a0 + 8 < end) ? p[1] : 0;
-    const uint64_t q2 = (a0 + 16 < end) ? p[2] : 0;
+    const uint64_t q1 = *((a0 + 8 < end) ? p + 1 : p);
+    const uint64_t q2 = *((a0 + 16 < end) ? p + 2 : p);
     Window16 w;
     w.lo = sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0;
     w.hi = sh ? (q1 >> sh) | (q2 << (64 - sh)) : q1;
@@ -161,21 +169,22 @@ __device__ __forceinline__ uint32_t parse_run(const uint8_t *s, uint64_t len, ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1: header scan -- one lane per segment.  COUNT pass: runs and values per segment.
-// EMIT pass (after the segment prefix sums): the run table and the first run of every window.
+// K1: header scan -- one lane per segment.  COUNT pass: runs and values per segment, finished by
+// a workgroup-local prefix sum.  EMIT pass (after the scan of the workgroup totals): the run
+// table and, per 512-value window, its first run.
 // ---------------------------------------------------------------------------------------------
 
 template <bool EMIT>
-__global__ __launch_bounds__(256) void rlev2_scan_kernel(
+__global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
-    uint32_t n_seg, int is_signed, SegCount *__restrict__ seg_count,
-    const SegOffset *__restrict__ seg_off, RunEntry *__restrict__ runs,
-    uint32_t *__restrict__ group_first, uint32_t n_group_slots) {
-    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seg >= n_seg) return;
-    // offset 0 is always an entry: segment 0 starts there whatever entries[0] says
-    uint64_t pos = (entries && seg > 0) ? entries[seg] : 0;
-    const uint64_t end = (entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
+    uint32_t n_seg, int is_signed, SegTable t, RunEntry *__restrict__ runs,
+    uint32_t *__restrict__ group_first, RunEntry *__restrict__ group_run,
+    uint32_t n_group_slots) {
+    const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
+    const bool valid = seg < n_seg;
+    // the first entry is taken to be offset 0 whatever its value
+    uint64_t pos = (valid && entries && seg > 0) ? entries[seg] : 0;
+    const uint64_t end = (valid && entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
     const bool last_seg = seg + 1 == n_seg;
     if (pos > len) pos = len;
 
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256) void rlev2_scan_kernel(
         uint32_t n_runs = 0, last_len = 0, status = SEG_OK;
         uint64_t n_vals = 0;
         if (end > len || end < pos) status = SEG_MISALIGNED;
-        while (status == SEG_OK && pos < end) {
+        while (valid && status == SEG_OK && pos < end) {
             ParsedRun r;
             status = parse_run(s, len, pos, is_signed, r);
             if (status != SEG_OK) break;
@@ -193,16 +202,11 @@ __global__ __launch_bounds__(256) void rlev2_scan_kernel(
             pos = r.run_end;
         }
         if (status == SEG_OK && pos != end && !last_seg) status = SEG_MISALIGNED;
-        SegCount c;
-        c.n_runs = n_runs;
-        c.last_len = last_len;
-        c.status = status;
-        c.pad = 0;
-        c.n_vals = n_vals;
-        seg_count[seg] = c;
+        seg_publish(t, seg, n_seg, n_runs, last_len, status, n_vals);
     } else {
-        const uint32_t n_runs = seg_count[seg].n_runs;
-        const SegOffset so = seg_off[seg];
+        if (!valid) return;
+        const uint32_t n_runs = t.seg_count[seg].n_runs;
+        const SegOffset so = seg_global_offset(t, seg);
         uint64_t out_off = so.val_off;
         uint32_t run_idx = so.run_off;
         uint32_t prev_len = so.prev_len;  // 0 only before the very first run
@@ -218,7 +222,14 @@ __global__ __launch_bounds__(256) void rlev2_scan_kernel(
             // first run that starts inside its 512-value window?
             const uint64_t win = out_off >> WINDOW_SHIFT;
             const bool first = (out_off == 0) || (((out_off - prev_len) >> WINDOW_SHIFT) != win);
-            if (first && win < n_group_slots) group_first[win] = run_idx;
+            if (first && win < n_group_slots) {
+                group_first[win] = run_idx;
+                // the window's own copy, so that the value kernel needs no dependent table load;
+                // flagged when no other run starts in this window
+                RunEntry ge = e;
+                if (((out_off + r.len) >> WINDOW_SHIFT) != win) ge.desc |= DESC_SINGLE;
+                group_run[win] = ge;
+            }
             out_off += r.len;
             prev_len = r.len;
             run_idx++;
@@ -237,94 +248,89 @@ __global__ __launch_bounds__(256) void rlev2_scan_kernel(
             // sentinel's index (an empty group).
             const uint64_t g_end = (out_off + WINDOW - 1) >> WINDOW_SHIFT;
             uint64_t g = out_off == 0 ? 0 : ((out_off - prev_len) >> WINDOW_SHIFT) + 1;
-            for (; g <= g_end && g < n_group_slots; g++) group_first[g] = run_idx;
+            for (; g <= g_end && g < n_group_slots; g++) {
+                group_first[g] = run_idx;
+                group_run[g] = e;
+            }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: prefix sums over the segments (few: one per ~10k values) -- a single workgroup.
+// K2: prefix sums over the per-workgroup totals of the counting pass -- one workgroup.
 // ---------------------------------------------------------------------------------------------
 
 constexpr int SCAN_THREADS = 1024;
 
-template <typename T, typename Op>
-__device__ __forceinline__ T block_inclusive_scan(T v, T identity, Op op, T *wave_tot /*[16]*/,
-                                                  T &block_total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int d = 1; d < 64; d <<= 1) {
-        T up;
-        if constexpr (sizeof(T) == 8) up = (T)shfl_up64((uint64_t)v, d);
-        else up = (T)__shfl_up((uint32_t)v, d);
-        if (lane >= d) v = op(up, v);
-    }
-    __syncthreads();
-    if (lane == 63) wave_tot[wave] = v;
-    __syncthreads();
-    T prefix = identity, total = identity;
-    for (int i = 0; i < SCAN_THREADS / 64; i++) {
-        const T t = wave_tot[i];
-        if (i < wave) prefix = op(prefix, t);
-        total = op(total, t);
-    }
-    block_total = total;
-    return op(prefix, v);
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void segment_scan_kernel(
-    const SegCount *__restrict__ seg_count, uint32_t n_seg, uint64_t num_values,
-    SegOffset *__restrict__ seg_off, ScanTotals *__restrict__ totals) {
-    __shared__ uint64_t wave_tot[SCAN_THREADS / 64];
+__global__ __launch_bounds__(SCAN_THREADS) void block_totals_scan_kernel(SegTable t, uint32_t n_blocks,
+                                                                         uint64_t num_values) {
+    __shared__ uint64_t w_vals[SCAN_THREADS / 64];
+    __shared__ uint64_t w_runs[SCAN_THREADS / 64];
+    __shared__ uint64_t w_key[SCAN_THREADS / 64];
     __shared__ uint32_t first_bad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) first_bad = 0xFFFFFFFFu;
-    __syncthreads();
-    auto add = [](uint64_t a, uint64_t b) { return a + b; };
-    auto mx = [](uint64_t a, uint64_t b) { return a > b ? a : b; };
     uint64_t carry_vals = 0, carry_runs = 0, carry_key = 0;
-    for (uint32_t base = 0; base < n_seg; base += SCAN_THREADS) {
-        const uint32_t i = base + threadIdx.x;
-        SegCount c;
-        c.n_runs = 0; c.last_len = 0; c.status = SEG_OK; c.pad = 0; c.n_vals = 0;
-        if (i < n_seg) c = seg_count[i];
-        // "length of the last run before segment i" = last_len of the most recent non-empty
-        // segment j < i: a prefix maximum over keys (j + 1, last_len_j) of the elements shifted
-        // right by one, so that the inclusive scan below is exclusive in i.
-        uint64_t key = 0;
-        if (i > 0 && i < n_seg) {
-            const SegCount p = seg_count[i - 1];
-            if (p.n_runs) key = ((uint64_t)i << 10) | p.last_len;
+    for (uint32_t base = 0; base < n_blocks; base += SCAN_THREADS) {
+        const uint32_t b = base + threadIdx.x;
+        BlockTotals bt;
+        bt.n_vals = 0; bt.n_runs = 0; bt.last_len = 0; bt.bad_local_end = 0;
+        bt.bad_seg = 0xFFFFFFFFu; bt.bad_status = SEG_OK;
+        if (b < n_blocks) bt = t.blk[b];
+        uint64_t iv = bt.n_vals, ir = bt.n_runs;
+        uint64_t ik = bt.n_runs ? (((uint64_t)b + 1) << 10) | bt.last_len : 0;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t uv = shfl_up64(iv, d), ur = shfl_up64(ir, d), uk = shfl_up64(ik, d);
+            if (lane >= d) {
+                iv += uv;
+                ir += ur;
+                ik = ik > uk ? ik : uk;
+            }
         }
-        uint64_t tv, tr, tk;
-        const uint64_t iv = block_inclusive_scan<uint64_t>(c.n_vals, 0, add, wave_tot, tv);
-        const uint64_t ir = block_inclusive_scan<uint64_t>(c.n_runs, 0, add, wave_tot, tr);
-        const uint64_t ik = block_inclusive_scan<uint64_t>(key, 0, mx, wave_tot, tk);
-        if (i < n_seg) {
-            SegOffset o;
-            o.val_off = carry_vals + iv - c.n_vals;
-            o.run_off = (uint32_t)(carry_runs + ir - c.n_runs);
-            o.prev_len = (uint32_t)(mx(carry_key, ik) & 1023);
-            seg_off[i] = o;
+        __syncthreads();  // the previous round's reads of w_* are done
+        if (lane == 63) { w_vals[wave] = iv; w_runs[wave] = ir; w_key[wave] = ik; }
+        __syncthreads();
+        uint64_t pv = 0, pr = 0, pk = 0, tv = 0, tr = 0, tk = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; w++) {
+            if (w < wave) { pv += w_vals[w]; pr += w_runs[w]; pk = pk > w_key[w] ? pk : w_key[w]; }
+            tv += w_vals[w];
+            tr += w_runs[w];
+            tk = tk > w_key[w] ? tk : w_key[w];
+        }
+        uint64_t incl_key = ik > pk ? ik : pk;
+        incl_key = incl_key > carry_key ? incl_key : carry_key;
+        uint64_t excl_key = shfl_up64(incl_key, 1);
+        if (lane == 0) excl_key = pk > carry_key ? pk : carry_key;
+        if (b < n_blocks) {
+            BlockOffset o;
+            o.val_off = carry_vals + pv + iv - bt.n_vals;
+            o.run_off = (uint32_t)(carry_runs + pr + ir - bt.n_runs);
+            o.prev_len = (uint32_t)(excl_key & 1023);
+            t.boff[b] = o;
             // a stopped walk matters only if values past it are still wanted
-            if (c.status != SEG_OK && o.val_off + c.n_vals < num_values) atomicMin(&first_bad, i);
+            if (bt.bad_seg != 0xFFFFFFFFu && o.val_off + bt.bad_local_end < num_values)
+                atomicMin(&first_bad, b);
         }
         carry_vals += tv;
         carry_runs += tr;
-        carry_key = mx(carry_key, tk);
+        carry_key = carry_key > tk ? carry_key : tk;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        ScanTotals t;
-        t.total_vals = carry_vals;
-        t.total_runs = carry_runs;
-        t.error = ORCD_OK;
-        t.error_seg = first_bad;
-        t.pad = 0;
+        ScanTotals tt;
+        tt.total_vals = carry_vals;
+        tt.total_runs = carry_runs;
+        tt.error = ORCD_OK;
+        tt.error_seg = 0xFFFFFFFFu;
+        tt.pad = 0;
         if (first_bad != 0xFFFFFFFFu) {
-            t.error = seg_count[first_bad].status == SEG_TOO_LONG ? ORCD_UNSUPPORTED : ORCD_OUT_OF_SPEC;
+            const BlockTotals bt = t.blk[first_bad];
+            tt.error = bt.bad_status == SEG_TOO_LONG ? ORCD_UNSUPPORTED : ORCD_OUT_OF_SPEC;
+            tt.error_seg = bt.bad_seg;
         } else if (carry_vals < num_values) {
-            t.error = ORCD_OUT_OF_SPEC;  // the stream ends before num_values values
+            tt.error = ORCD_OUT_OF_SPEC;  // the stream ends before num_values values
         }
-        *totals = t;
+        *t.totals = tt;
     }
 }
 
@@ -332,22 +338,75 @@ __global__ __launch_bounds__(SCAN_THREADS) void segment_scan_kernel(
 // K3: value expansion -- one wavefront per group (the runs that start inside one aligned window
 // of 512 output values).  Lane i of step j owns output values 128*j + 2*i and 128*j + 2*i + 1 of
 // the window, so every store instruction writes 1 KiB of consecutive, 16-byte aligned output.
+//
+// The packed bytes a window needs are staged into a wavefront-private LDS slice with 16-byte
+// loads and byte-swapped per dword on the way in, so that the big-endian bit stream reads as
+// plain 32-bit words.  A group that consists of a single run -- the bulk of any large column,
+// whose runs hold 512 values -- takes a path where every run field is wave-uniform.
 // ---------------------------------------------------------------------------------------------
 
 constexpr int VAL_WAVES = 4;                   // wavefronts per workgroup
-constexpr uint32_t STAGE_BYTES = 2560;         // LDS staging slice per wavefront
+constexpr uint32_t STAGE_BYTES = 4096 + 128;   // LDS slice per wavefront: any single run fits
 constexpr uint32_t STAGE_WORDS = STAGE_BYTES / 4 + 4;  // + padding for the 3-word extraction
 
-// Field of `w` bits (1..64) at bit `bitpos` of the big-endian bit stream formed by `words`.
-// GUARD: touch only words that hold wanted bits (global memory: a word past them may be unmapped).
-template <bool GUARD>
-__device__ __forceinline__ uint64_t extract_bits(const uint32_t *words, uint64_t bitpos, uint32_t w) {
+struct Wave {
+    const uint8_t *s;      // stream
+    uint32_t *lds;         // this wavefront's staging slice
+    int64_t *out;
+    uint64_t num_values;
+    int lane;
+    int is_signed;
+    bool out_aligned;      // out is 16-byte aligned
+};
+
+// Copies stream bytes [b0, b1) into the LDS slice; returns the stream offset that LDS byte 0
+// stands for (up to 15 bytes before b0; it may wrap below zero, only differences are used).
+// Reads whole aligned 16-byte chunks: each holds at least one byte of [b0, b1).
+__device__ __forceinline__ uint64_t stage_bytes(const Wave &wv, uint64_t b0, uint64_t b1) {
+    const uint32_t skew = (uint32_t)((uintptr_t)(wv.s + b0) & 15);
+    const uint4 *src = (const uint4 *)(wv.s + b0 - skew);
+    const uint32_t n16 = (uint32_t)((b1 - b0 + skew + 15) >> 4);
+    for (uint32_t c = wv.lane; c < n16; c += 64) {
+        uint4 v = src[c];
+        v.x = __builtin_bswap32(v.x);
+        v.y = __builtin_bswap32(v.y);
+        v.z = __builtin_bswap32(v.z);
+        v.w = __builtin_bswap32(v.w);
+        ((uint4 *)wv.lds)[c] = v;
+    }
+    // LDS operations of one wavefront execute in order; this only keeps the compiler from
+    // moving the reads below above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return b0 - skew;
+}
+
+// Field of w bits (1..32) at bit `bit` of the staged (byte-swapped) words.
+__device__ __forceinline__ uint32_t lds_bits32(const uint32_t *lds, uint32_t bit, uint32_t w) {
+    const uint32_t d = bit >> 5, sh = bit & 31;
+    const uint64_t x = ((uint64_t)lds[d] << 32) | lds[d + 1];
+    return (uint32_t)((x << sh) >> (64 - w));
+}
+
+// Field of w bits (1..64).
+__device__ __forceinline__ uint64_t lds_bits64(const uint32_t *lds, uint32_t bit, uint32_t w) {
+    const uint32_t d = bit >> 5, sh = bit & 31;
+    const uint64_t x = ((uint64_t)lds[d] << 32) | lds[d + 1];
+    uint64_t v = x << sh;
+    if (sh) v |= (uint64_t)lds[d + 2] >> (32 - sh);
+    return v >> (64 - w);
+}
+
+// Field of w bits (1..64) at bit `bitpos` of the big-endian bit stream starting at `words`, read
+// straight from global memory.  Only words that hold wanted bits are touched: one past them may
+// be unmapped.
+__device__ __forceinline__ uint64_t global_bits(const uint32_t *words, uint64_t bitpos, uint32_t w) {
     const uint64_t d = bitpos >> 5;
     const uint32_t sh = (uint32_t)bitpos & 31;
     const uint32_t need = sh + w;
     const uint32_t w0 = __builtin_bswap32(words[d]);
-    const uint32_t w1 = (!GUARD || need > 32) ? __builtin_bswap32(words[d + 1]) : 0;
-    const uint32_t w2 = (!GUARD || need > 64) ? __builtin_bswap32(words[d + 2]) : 0;
+    const uint32_t w1 = need > 32 ? __builtin_bswap32(words[d + 1]) : 0;
+    const uint32_t w2 = need > 64 ? __builtin_bswap32(words[d + 2]) : 0;
     const uint64_t hi = ((uint64_t)w0 << 32) | w1;
     uint64_t v = hi << sh;
     if (sh) v |= (uint64_t)w2 >> (32 - sh);
@@ -365,222 +424,420 @@ __device__ __forceinline__ void payload_range(uint32_t kind, uint32_t w, uint32_
     b1 = ((uint64_t)last * w + 7) >> 3;
 }
 
+// Two adjacent output values of one lane.
+__device__ __forceinline__ void store_pair(const Wave &wv, uint64_t e0, uint64_t v0, uint64_t v1,
+                                           bool a0, bool a1) {
+    int64_t *dst = wv.out + e0;
+    if (a0 && a1 && wv.out_aligned) {
+        *(ulonglong2 *)dst = make_ulonglong2(v0, v1);
+    } else {
+        if (a0) dst[0] = (int64_t)v0;
+        if (a1) dst[1] = (int64_t)v1;
+    }
+}
+
+// Inclusive prefix sum over the 64 lanes.
+__device__ __forceinline__ uint64_t wave_scan_u64(uint64_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = shfl_up64(v, d);
+        if (lane >= d) v += up;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(v, d);
+        if (lane >= d) v += up;
+    }
+    return v;
+}
+
+// PatchedBase: overwrites the patched positions of one run (all fields wave-uniform) after its
+// unpatched values have been written.  Lane j takes patch-list entry j.
+__device__ __forceinline__ void apply_patches(const Wave &wv, uint64_t desc, uint64_t base,
+                                              uint64_t aux, uint64_t run_out) {
+    const uint32_t w = desc_width(desc), rlen = desc_len(desc);
+    const uint32_t pw = pb_patch_width(aux), pll = pb_list_len(aux), cfb = pb_entry_bits(aux);
+    const uint8_t *p = wv.s + desc_payload(desc);
+    const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
+    const uint32_t *words = (const uint32_t *)(p - sk);
+    const uint64_t list_bit = (uint64_t)sk * 8 + (((uint64_t)w * rlen + 7) >> 3) * 8;
+    uint64_t gap = 0, patch = 0;
+    if ((uint32_t)wv.lane < pll) {
+        const uint64_t entry = global_bits(words, list_bit + (uint64_t)wv.lane * cfb, cfb);
+        gap = pw >= 64 ? 0 : entry >> pw;
+        patch = pw >= 64 ? entry : entry & ((1ull << pw) - 1);
+    }
+    const uint32_t posn = wave_scan_u32((uint32_t)gap, wv.lane);  // position = sum of the gaps
+    const bool filler = gap == 255 && patch == 0;                 // only extends the gap
+    if ((uint32_t)wv.lane < pll && !filler && posn < rlen && run_out + posn < wv.num_values) {
+        uint64_t m = global_bits(words, (uint64_t)sk * 8 + (uint64_t)posn * w, w);
+        if (w < 64) m |= patch << w;
+        wv.out[run_out + posn] = (int64_t)(base + m);
+    }
+}
+
+// ---- a group that is one run: every run field is wave-uniform -----------------------------------
+//
+// FULL: the window is entirely this run's and `out` is 16-byte aligned, so there is no lane
+// masking and every store is a 16-byte one.  lo_rel / hi_rel bound the active values inside the
+// window otherwise.
+
+template <bool FULL>
+__device__ __forceinline__ void store_window_pair(const Wave &wv, int64_t *wout, uint32_t i_rel,
+                                                  uint64_t v0, uint64_t v1, uint32_t lo_rel,
+                                                  uint32_t hi_rel) {
+    if (FULL) {
+        *(ulonglong2 *)(wout + i_rel) = make_ulonglong2(v0, v1);
+    } else {
+        const bool a0 = i_rel >= lo_rel && i_rel < hi_rel;
+        const bool a1 = i_rel + 1 >= lo_rel && i_rel + 1 < hi_rel;
+        if (a0 && a1 && wv.out_aligned) {
+            *(ulonglong2 *)(wout + i_rel) = make_ulonglong2(v0, v1);
+        } else {
+            if (a0) wout[i_rel] = (int64_t)v0;
+            if (a1) wout[i_rel + 1] = (int64_t)v1;
+        }
+    }
+}
+
+// Direct and (unpatched) PatchedBase values of one window.  bit_lane: LDS bit position of the
+// packed field of this lane's first value of step 0.
+template <bool FULL, bool WIDE>
+__device__ __forceinline__ void direct_window(const Wave &wv, int64_t *wout, uint32_t w, bool zz,
+                                              uint64_t add, uint32_t bit_lane, uint32_t lo_rel,
+                                              uint32_t hi_rel) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i_rel = 128u * j + 2u * wv.lane;
+        uint32_t bA = bit_lane + (128u * j) * w, bB = bA + w;
+        if (!FULL) {  // keep the LDS reads of inactive lanes inside the slice
+            if (!(i_rel >= lo_rel && i_rel < hi_rel)) bA = 0;
+            if (!(i_rel + 1 >= lo_rel && i_rel + 1 < hi_rel)) bB = 0;
+        }
+        uint64_t v0, v1;
+        if (!WIDE) {
+            const uint32_t m0 = lds_bits32(wv.lds, bA, w), m1 = lds_bits32(wv.lds, bB, w);
+            if (zz) {  // zigzag in 32 bits, then sign-extend
+                v0 = (uint64_t)(int64_t)(int32_t)((m0 >> 1) ^ (0u - (m0 & 1u)));
+                v1 = (uint64_t)(int64_t)(int32_t)((m1 >> 1) ^ (0u - (m1 & 1u)));
+            } else {
+                v0 = add + m0;
+                v1 = add + m1;
+            }
+        } else {
+            const uint64_t m0 = lds_bits64(wv.lds, bA, w), m1 = lds_bits64(wv.lds, bB, w);
+            v0 = zz ? zigzag(m0) : add + m0;
+            v1 = zz ? zigzag(m1) : add + m1;
+        }
+        store_window_pair<FULL>(wv, wout, i_rel, v0, v1, lo_rel, hi_rel);
+    }
+}
+
+// Delta values of one window: value[i] = base (+ delta_base for i >= 1) +/- the packed deltas up
+// to i.  idx0: index in the run of this lane's first value of step 0 (negative before the run).
+template <bool FULL, bool WIDE>
+__device__ __forceinline__ void delta_window(const Wave &wv, int64_t *wout, uint32_t w, bool neg,
+                                             uint64_t base, uint64_t delta_base, uint32_t bit_lane,
+                                             int32_t idx0, uint32_t lo_rel, uint32_t hi_rel,
+                                             uint64_t &carry) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i_rel = 128u * j + 2u * wv.lane;
+        const int32_t i0 = idx0 + 128 * j, i1 = i0 + 1;
+        const bool a0 = FULL || (i_rel >= lo_rel && i_rel < hi_rel);
+        const bool a1 = FULL || (i_rel + 1 >= lo_rel && i_rel + 1 < hi_rel);
+        const bool p0 = a0 && i0 >= 2, p1 = a1 && i1 >= 2;
+        const uint32_t bA = p0 ? bit_lane + (128u * j) * w : 0u;
+        const uint32_t bB = p1 ? bit_lane + (128u * j + 1) * w : 0u;
+        uint64_t m0, m1;
+        if (!WIDE) {
+            m0 = lds_bits32(wv.lds, bA, w);
+            m1 = lds_bits32(wv.lds, bB, w);
+        } else {
+            m0 = lds_bits64(wv.lds, bA, w);
+            m1 = lds_bits64(wv.lds, bB, w);
+        }
+        // per-value step: base for the first value, delta_base for the second
+        const uint64_t c0 = p0 ? (neg ? 0 - m0 : m0) : (a0 ? (i0 == 0 ? base : delta_base) : 0);
+        const uint64_t c1 = p1 ? (neg ? 0 - m1 : m1) : (a1 ? (i1 == 0 ? base : delta_base) : 0);
+        const uint64_t v1 = carry + wave_scan_u64(c0 + c1, wv.lane);
+        const uint64_t v0 = v1 - c1;
+        carry = readlane64(v1, 63);
+        store_window_pair<FULL>(wv, wout, i_rel, v0, v1, lo_rel, hi_rel);
+    }
+}
+
+// ShortRepeat (step 0) and Delta without packed deltas: base + i * step.
+template <bool FULL>
+__device__ __forceinline__ void linear_window(const Wave &wv, int64_t *wout, uint64_t base,
+                                              uint64_t step, int32_t idx0, uint32_t lo_rel,
+                                              uint32_t hi_rel) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i_rel = 128u * j + 2u * wv.lane;
+        const uint64_t i0 = (uint64_t)(int64_t)(idx0 + 128 * j);
+        store_window_pair<FULL>(wv, wout, i_rel, base + i0 * step, base + (i0 + 1) * step, lo_rel,
+                                hi_rel);
+    }
+}
+
+__device__ __forceinline__ void decode_single_run(const Wave &wv, uint64_t desc, uint64_t run_out,
+                                                  uint64_t base, uint64_t aux) {
+    const uint32_t kind = desc_kind(desc), w = desc_width(desc), rlen = desc_len(desc);
+    uint64_t run_end = run_out + rlen;
+    if (run_end > wv.num_values) run_end = wv.num_values;
+    const bool packed_kind = w != 0 && kind != KIND_SHORT_REPEAT;
+    uint64_t carry = 0;  // Delta: value of the element before the current step
+    for (uint64_t wbase = (run_out >> WINDOW_SHIFT) << WINDOW_SHIFT; wbase < run_end; wbase += WINDOW) {
+        // active values of this window, relative to its start
+        const uint32_t lo_rel = wbase > run_out ? 0u : (uint32_t)(run_out - wbase);
+        const uint32_t hi_rel = (wbase + WINDOW) < run_end ? WINDOW : (uint32_t)(run_end - wbase);
+        const bool full = lo_rel == 0 && hi_rel == WINDOW && wv.out_aligned;
+        // index in the run of the window's first value (negative before the run)
+        const int32_t win_idx = (int32_t)(int64_t)(wbase - run_out);
+        uint32_t bit0 = 0;  // bit position in LDS of packed field 0 of the run (modulo 2^32)
+        if (packed_kind) {
+            uint64_t b0, b1;
+            payload_range(kind, w, (uint32_t)(win_idx + (int32_t)lo_rel),
+                          (uint32_t)(win_idx + (int32_t)hi_rel), b0, b1);
+            if (b1 > b0) {
+                const uint64_t origin = stage_bytes(wv, desc_payload(desc) + b0, desc_payload(desc) + b1);
+                bit0 = (uint32_t)((desc_payload(desc) - origin) << 3);
+            }
+        }
+        int64_t *wout = wv.out + wbase;
+        const int32_t idx0 = win_idx + 2 * wv.lane;
+        if (kind == KIND_DIRECT || kind == KIND_PATCHED_BASE) {
+            const uint64_t add = kind == KIND_PATCHED_BASE ? base : 0;
+            const bool zz = kind == KIND_DIRECT && wv.is_signed;
+            const uint32_t bit_lane = bit0 + (uint32_t)idx0 * w;
+            if (w <= 32) {
+                if (full) direct_window<true, false>(wv, wout, w, zz, add, bit_lane, lo_rel, hi_rel);
+                else direct_window<false, false>(wv, wout, w, zz, add, bit_lane, lo_rel, hi_rel);
+            } else {
+                if (full) direct_window<true, true>(wv, wout, w, zz, add, bit_lane, lo_rel, hi_rel);
+                else direct_window<false, true>(wv, wout, w, zz, add, bit_lane, lo_rel, hi_rel);
+            }
+        } else if (kind == KIND_DELTA && w != 0) {
+            const bool neg = desc_delta_neg(desc) != 0;
+            const uint32_t bit_lane = bit0 + (uint32_t)(idx0 - 2) * w;
+            if (w <= 32) {
+                if (full) delta_window<true, false>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
+                else delta_window<false, false>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
+            } else {
+                if (full) delta_window<true, true>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
+                else delta_window<false, true>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
+            }
+        } else {
+            const uint64_t step = kind == KIND_DELTA ? aux : 0;
+            if (full) linear_window<true>(wv, wout, base, step, idx0, lo_rel, hi_rel);
+            else linear_window<false>(wv, wout, base, step, idx0, lo_rel, hi_rel);
+        }
+    }
+    if (kind == KIND_PATCHED_BASE) {
+        __builtin_amdgcn_s_waitcnt(0);  // the unpatched values are written
+        apply_patches(wv, desc, base, aux, run_out);
+    }
+}
+
+// ---- any group: up to 64 runs at a time, one per lane ------------------------------------------
+
 struct RunFields {
     uint64_t desc, base, aux;
     uint32_t rel_out;  // out_off relative to the batch's first value
 };
 
-__global__ __launch_bounds__(VAL_WAVES * 64) void rlev2_values_kernel(
+__device__ __forceinline__ void decode_run_batch(const Wave &wv, const RunEntry *runs, uint32_t rb,
+                                                 uint32_t nb) {
+    const int lane = wv.lane;
+    // lane k holds run rb + k of the batch
+    RunEntry me;
+    me.desc = make_desc(0, KIND_SHORT_REPEAT, 0, 1, 0);
+    me.out_off = ~0ull;
+    me.base = 0;
+    me.aux = 0;
+    if ((uint32_t)lane < nb) me = runs[rb + lane];
+    const uint32_t my_kind = desc_kind(me.desc), my_w = desc_width(me.desc);
+    const uint32_t my_len = desc_len(me.desc);
+    const uint64_t batch_beg = readlane64(me.out_off, 0);
+    uint64_t batch_end = readlane64(me.out_off + my_len, (int)nb - 1);
+    if (batch_end > wv.num_values) batch_end = wv.num_values;
+    const uint32_t my_rel = (uint32_t)lane < nb ? (uint32_t)(me.out_off - batch_beg) : 0xFFFFFFFFu;
+    uint64_t carry = 0;  // running value of a Delta run that continues into the next step
+
+    for (uint64_t wbase = (batch_beg >> WINDOW_SHIFT) << WINDOW_SHIFT; wbase < batch_end;
+         wbase += WINDOW) {
+        const uint64_t lo = wbase > batch_beg ? wbase : batch_beg;
+        const uint64_t hi = (wbase + WINDOW) < batch_end ? (wbase + WINDOW) : batch_end;
+
+        // ---- which payload bytes does this window need? -----------------------------------
+        uint64_t need_b0 = 0, need_b1 = 0;
+        bool needs = false, scans = false;
+        if ((uint32_t)lane < nb && me.out_off < hi && me.out_off + my_len > lo &&
+            my_kind != KIND_SHORT_REPEAT && my_w != 0) {
+            const uint32_t first = me.out_off >= lo ? 0u : (uint32_t)(lo - me.out_off);
+            const uint32_t last = (me.out_off + my_len) <= hi ? my_len : (uint32_t)(hi - me.out_off);
+            uint64_t b0, b1;
+            payload_range(my_kind, my_w, first, last, b0, b1);
+            needs = b1 > b0;
+            need_b0 = desc_payload(me.desc) + b0;
+            need_b1 = desc_payload(me.desc) + b1;
+            scans = my_kind == KIND_DELTA;
+        }
+        const uint64_t need_mask = __ballot(needs);
+        const bool any_scan = __ballot(scans) != 0;
+        bool use_lds = false;
+        uint64_t lds_origin = 0;
+        if (need_mask) {
+            const int k_lo = __ffsll((unsigned long long)need_mask) - 1;
+            const int k_hi = 63 - __clzll((unsigned long long)need_mask);
+            const uint64_t span_b0 = readlane64(need_b0, k_lo);
+            const uint64_t span_b1 = readlane64(need_b1, k_hi);
+            if (span_b1 - span_b0 + 15 <= STAGE_BYTES) {
+                use_lds = true;
+                lds_origin = stage_bytes(wv, span_b0, span_b1);
+            }
+        }
+
+        // ---- decode the window: 4 steps of 128 values -------------------------------------
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t e0 = wbase + 128u * j + 2u * lane;
+            uint64_t c[2];
+            bool head[2], act[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const uint64_t e = e0 + t;
+                act[t] = e >= lo && e < hi;
+                const uint32_t e_rel = act[t] ? (uint32_t)(e - batch_beg) : (uint32_t)(lo - batch_beg);
+                // largest k with rel_out[k] <= e_rel (lanes >= nb hold 0xFFFFFFFF)
+                int k = 0;
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) {
+                    const uint32_t v = __shfl(my_rel, k + sft);
+                    if (v <= e_rel) k += sft;
+                }
+                RunFields f;
+                f.rel_out = __shfl(my_rel, k);
+                f.desc = shfl64(me.desc, k);
+                f.base = shfl64(me.base, k);
+                f.aux = shfl64(me.aux, k);
+                const uint32_t kind = desc_kind(f.desc), w = desc_width(f.desc);
+                const uint32_t idx = e_rel - f.rel_out;
+                uint64_t val = f.base;
+                bool hd = true;
+                // index of the packed field that belongs to this value, if any
+                uint32_t fidx = idx;
+                bool packed = act[t] && w != 0 && (kind == KIND_DIRECT || kind == KIND_PATCHED_BASE);
+                if (kind == KIND_DELTA) {
+                    if (w == 0) {
+                        val = f.base + (uint64_t)idx * f.aux;  // fixed delta
+                    } else if (idx == 1) {
+                        val = f.aux;
+                        hd = false;
+                    } else if (idx >= 2) {
+                        packed = act[t];
+                        fidx = idx - 2;
+                        hd = false;
+                    }
+                }
+                if (packed) {
+                    uint64_t m;
+                    if (use_lds) {
+                        const uint32_t bit = (uint32_t)((desc_payload(f.desc) - lds_origin) << 3) + fidx * w;
+                        m = lds_bits64(wv.lds, bit, w);
+                    } else {
+                        const uint8_t *p = wv.s + desc_payload(f.desc);
+                        const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
+                        m = global_bits((const uint32_t *)(p - sk), (uint64_t)sk * 8 + (uint64_t)fidx * w, w);
+                    }
+                    if (kind == KIND_DIRECT) val = wv.is_signed ? zigzag(m) : m;
+                    else if (kind == KIND_PATCHED_BASE) val = f.base + m;
+                    else val = desc_delta_neg(f.desc) ? 0 - m : m;
+                }
+                c[t] = val;
+                head[t] = hd || !act[t];
+            }
+
+            uint64_t v0 = c[0], v1 = c[1];
+            if (any_scan) {
+                // segmented inclusive sum across the step: heads restart the sum
+                bool ph = head[0] || head[1];
+                uint64_t ps = head[1] ? c[1] : c[0] + c[1];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint64_t s_up = shfl_up64(ps, d);
+                    const uint32_t h_up = __shfl_up((uint32_t)ph, d);
+                    if (lane >= d) {
+                        if (!ph) ps += s_up;
+                        ph = ph || h_up;
+                    }
+                }
+                uint64_t xs = shfl_up64(ps, 1);
+                uint32_t xh = __shfl_up((uint32_t)ph, 1);
+                if (lane == 0) { xs = 0; xh = 0; }
+                const uint64_t prefix = xh ? xs : xs + carry;
+                v0 = head[0] ? c[0] : prefix + c[0];
+                v1 = head[1] ? c[1] : v0 + c[1];
+                carry = readlane64(v1, 63);
+            }
+            store_pair(wv, e0, v0, v1, act[0], act[1]);
+        }
+    }
+
+    // ---- PatchedBase: overwrite the patched positions ----------------------------------------
+    uint64_t pb_mask = __ballot((uint32_t)lane < nb && my_kind == KIND_PATCHED_BASE);
+    if (pb_mask) {
+        __builtin_amdgcn_s_waitcnt(0);  // the unpatched values of this batch are written
+        while (pb_mask) {
+            const int k = __ffsll((unsigned long long)pb_mask) - 1;
+            pb_mask &= pb_mask - 1;
+            apply_patches(wv, readlane64(me.desc, k), readlane64(me.base, k), readlane64(me.aux, k),
+                          readlane64(me.out_off, k));
+        }
+    }
+}
+
+__global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const RunEntry *__restrict__ runs,
-    const uint32_t *__restrict__ group_first, uint32_t n_groups, uint32_t n_runs,
-    uint64_t num_values, int is_signed, int64_t *__restrict__ out) {
+    const uint32_t *__restrict__ group_first, const RunEntry *__restrict__ group_run,
+    uint32_t n_groups, uint32_t n_runs, uint64_t num_values, int is_signed,
+    int64_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[VAL_WAVES][STAGE_WORDS];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t g = blockIdx.x * VAL_WAVES + wave;
     if (g >= n_groups) return;  // whole wavefront leaves; no workgroup barrier is used below
-    uint32_t *lds = stage[wave];
-    const bool out_aligned = (((uintptr_t)out) & 15) == 0;
+    Wave wv;
+    wv.s = s;
+    wv.lds = stage[wave];
+    wv.out = out;
+    wv.num_values = num_values;
+    wv.lane = threadIdx.x & 63;
+    wv.is_signed = is_signed;
+    wv.out_aligned = (((uintptr_t)out) & 15) == 0;
 
+    // The window's own copy of its first run: when that run is the only one starting in the
+    // window (flagged by the header scan) nothing else has to be loaded.
+    {
+        const RunEntry *e = group_run + g;  // wave-uniform address
+        const uint64_t desc = readfirstlane64(e->desc);
+        if (desc & DESC_SINGLE) {
+            decode_single_run(wv, desc, readfirstlane64(e->out_off), readfirstlane64(e->base),
+                              readfirstlane64(e->aux));
+            return;
+        }
+    }
     // the group's runs; clamped to the table so that a bad index can never walk off it
     uint32_t r1 = __builtin_amdgcn_readfirstlane(group_first[g + 1]);
     if (r1 > n_runs) r1 = n_runs;
     uint32_t r0 = __builtin_amdgcn_readfirstlane(group_first[g]);
     if (r0 > r1) r0 = r1;
-
     for (uint32_t rb = r0; rb < r1; rb += 64) {
         const uint32_t nb = (r1 - rb) < 64u ? (r1 - rb) : 64u;
-        // lane k holds run rb + k of the batch
-        RunEntry me;
-        me.desc = make_desc(0, KIND_SHORT_REPEAT, 0, 1, 0);
-        me.out_off = ~0ull;
-        me.base = 0;
-        me.aux = 0;
-        if ((uint32_t)lane < nb) me = runs[rb + lane];
-        const uint32_t my_kind = desc_kind(me.desc), my_w = desc_width(me.desc);
-        const uint32_t my_len = desc_len(me.desc);
-        const uint64_t batch_beg = readlane64(me.out_off, 0);
-        uint64_t batch_end = readlane64(me.out_off + my_len, (int)nb - 1);
-        if (batch_end > num_values) batch_end = num_values;
-        const uint32_t my_rel = (uint32_t)lane < nb ? (uint32_t)(me.out_off - batch_beg) : 0xFFFFFFFFu;
-        uint64_t carry = 0;  // running value of a Delta run that continues into the next step
-
-        for (uint64_t wbase = (batch_beg >> WINDOW_SHIFT) << WINDOW_SHIFT; wbase < batch_end;
-             wbase += WINDOW) {
-            const uint64_t lo = wbase > batch_beg ? wbase : batch_beg;
-            const uint64_t hi = (wbase + WINDOW) < batch_end ? (wbase + WINDOW) : batch_end;
-
-            // ---- which payload bytes does this window need? -------------------------------
-            uint64_t need_b0 = 0, need_b1 = 0;
-            bool needs = false, scans = false;
-            if ((uint32_t)lane < nb && me.out_off < hi && me.out_off + my_len > lo &&
-                my_kind != KIND_SHORT_REPEAT && my_w != 0) {
-                const uint32_t first = me.out_off >= lo ? 0u : (uint32_t)(lo - me.out_off);
-                const uint32_t last = (me.out_off + my_len) <= hi ? my_len : (uint32_t)(hi - me.out_off);
-                uint64_t b0, b1;
-                payload_range(my_kind, my_w, first, last, b0, b1);
-                needs = b1 > b0;
-                need_b0 = desc_payload(me.desc) + b0;
-                need_b1 = desc_payload(me.desc) + b1;
-                scans = my_kind == KIND_DELTA;
-            }
-            const uint64_t need_mask = __ballot(needs);
-            const bool any_scan = __ballot(scans) != 0;
-            bool use_lds = false;
-            uint64_t lds_origin = 0;  // stream offset of LDS byte 0 (may precede the stream by <16)
-            if (need_mask) {
-                const int k_lo = __ffsll((unsigned long long)need_mask) - 1;
-                const int k_hi = 63 - __clzll((unsigned long long)need_mask);
-                const uint64_t span_b0 = readlane64(need_b0, k_lo);
-                const uint64_t span_b1 = readlane64(need_b1, k_hi);
-                const uint32_t skew = (uint32_t)((uintptr_t)(s + span_b0) & 15);
-                const uint64_t span = span_b1 - span_b0 + skew;
-                if (span <= STAGE_BYTES) {
-                    use_lds = true;
-                    lds_origin = span_b0 - skew;  // wraps below zero harmlessly: only differences are used
-                    const uint4 *src = (const uint4 *)(s + span_b0 - skew);
-                    const uint32_t n16 = (uint32_t)((span + 15) >> 4);
-                    for (uint32_t c = lane; c < n16; c += 64) ((uint4 *)lds)[c] = src[c];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-
-            // ---- decode the window: 4 steps of 128 values ---------------------------------
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint64_t e0 = wbase + 128u * j + 2u * lane;
-                uint64_t c[2];
-                bool head[2], act[2];
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const uint64_t e = e0 + t;
-                    act[t] = e >= lo && e < hi;
-                    const uint32_t e_rel = act[t] ? (uint32_t)(e - batch_beg) : (uint32_t)(lo - batch_beg);
-                    RunFields f;
-                    if (nb == 1) {
-                        f.desc = readlane64(me.desc, 0);
-                        f.base = readlane64(me.base, 0);
-                        f.aux = readlane64(me.aux, 0);
-                        f.rel_out = 0;
-                    } else {
-                        // largest k with rel_out[k] <= e_rel (lanes >= nb hold 0xFFFFFFFF)
-                        int k = 0;
-#pragma unroll
-                        for (int sft = 32; sft >= 1; sft >>= 1) {
-                            const uint32_t v = __shfl(my_rel, k + sft);
-                            if (v <= e_rel) k += sft;
-                        }
-                        f.rel_out = __shfl(my_rel, k);
-                        f.desc = shfl64(me.desc, k);
-                        f.base = shfl64(me.base, k);
-                        f.aux = shfl64(me.aux, k);
-                    }
-                    const uint32_t kind = desc_kind(f.desc), w = desc_width(f.desc);
-                    const uint32_t idx = e_rel - f.rel_out;
-                    uint64_t val = f.base;
-                    bool hd = true;
-                    // index of the packed field that belongs to this value, if any
-                    uint32_t fidx = idx;
-                    bool packed = act[t] && w != 0 && (kind == KIND_DIRECT || kind == KIND_PATCHED_BASE);
-                    if (kind == KIND_DELTA) {
-                        if (w == 0) {
-                            val = f.base + (uint64_t)idx * f.aux;  // fixed delta
-                        } else if (idx == 1) {
-                            val = f.aux;
-                            hd = false;
-                        } else if (idx >= 2) {
-                            packed = act[t];
-                            fidx = idx - 2;
-                            hd = false;
-                        }
-                    }
-                    if (packed) {
-                        uint64_t m;
-                        if (use_lds) {
-                            const uint64_t bit = ((desc_payload(f.desc) - lds_origin) << 3) + (uint64_t)fidx * w;
-                            m = extract_bits<false>(lds, bit, w);
-                        } else {
-                            const uint8_t *p = s + desc_payload(f.desc);
-                            const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
-                            m = extract_bits<true>((const uint32_t *)(p - sk), (uint64_t)sk * 8 + (uint64_t)fidx * w, w);
-                        }
-                        if (kind == KIND_DIRECT) val = is_signed ? zigzag(m) : m;
-                        else if (kind == KIND_PATCHED_BASE) val = f.base + m;
-                        else val = desc_delta_neg(f.desc) ? 0 - m : m;
-                    }
-                    c[t] = val;
-                    head[t] = hd || !act[t];
-                }
-
-                uint64_t v0 = c[0], v1 = c[1];
-                if (any_scan) {
-                    // segmented inclusive sum across the step: heads restart the sum
-                    bool ph = head[0] || head[1];
-                    uint64_t ps = head[1] ? c[1] : c[0] + c[1];
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint64_t s_up = shfl_up64(ps, d);
-                        const uint32_t h_up = __shfl_up((uint32_t)ph, d);
-                        if (lane >= d) {
-                            if (!ph) ps += s_up;
-                            ph = ph || h_up;
-                        }
-                    }
-                    uint64_t xs = shfl_up64(ps, 1);
-                    uint32_t xh = __shfl_up((uint32_t)ph, 1);
-                    if (lane == 0) { xs = 0; xh = 0; }
-                    const uint64_t prefix = xh ? xs : xs + carry;
-                    v0 = head[0] ? c[0] : prefix + c[0];
-                    v1 = head[1] ? c[1] : v0 + c[1];
-                    carry = readlane64(v1, 63);
-                }
-
-                int64_t *dst = out + e0;
-                if (act[0] && act[1] && out_aligned) {
-                    *(ulonglong2 *)dst = make_ulonglong2(v0, v1);
-                } else {
-                    if (act[0]) dst[0] = (int64_t)v0;
-                    if (act[1]) dst[1] = (int64_t)v1;
-                }
-            }
-        }
-
-        // ---- PatchedBase: overwrite the patched positions ------------------------------------
-        uint64_t pb_mask = __ballot((uint32_t)lane < nb && my_kind == KIND_PATCHED_BASE);
-        if (pb_mask) {
-            __builtin_amdgcn_s_waitcnt(0);  // the unpatched values of this batch are written
-            while (pb_mask) {
-                const int k = __ffsll((unsigned long long)pb_mask) - 1;
-                pb_mask &= pb_mask - 1;
-                const uint64_t desc = readlane64(me.desc, k), base = readlane64(me.base, k);
-                const uint64_t aux = readlane64(me.aux, k), ro = readlane64(me.out_off, k);
-                const uint32_t w = desc_width(desc), rlen = desc_len(desc);
-                const uint32_t pw = pb_patch_width(aux), pll = pb_list_len(aux), cfb = pb_entry_bits(aux);
-                const uint8_t *p = s + desc_payload(desc);
-                const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
-                const uint32_t *words = (const uint32_t *)(p - sk);
-                const uint64_t list_bit = (uint64_t)sk * 8 + (((uint64_t)w * rlen + 7) >> 3) * 8;
-                uint64_t gap = 0, patch = 0;
-                if ((uint32_t)lane < pll) {
-                    const uint64_t entry = extract_bits<true>(words, list_bit + (uint64_t)lane * cfb, cfb);
-                    gap = pw >= 64 ? 0 : entry >> pw;
-                    patch = pw >= 64 ? entry : entry & ((1ull << pw) - 1);
-                }
-                uint32_t posn = (uint32_t)gap;  // position = inclusive sum of the gaps
-#pragma unroll
-                for (int d = 1; d < 32; d <<= 1) {
-                    const uint32_t up = __shfl_up(posn, d);
-                    if (lane >= d) posn += up;
-                }
-                const bool filler = gap == 255 && patch == 0;  // only extends the gap
-                if ((uint32_t)lane < pll && !filler && posn < rlen && ro + posn < num_values) {
-                    uint64_t m = w ? extract_bits<true>(words, (uint64_t)sk * 8 + (uint64_t)posn * w, w) : 0;
-                    if (w < 64) m |= patch << w;
-                    out[ro + posn] = (int64_t)(base + m);
-                }
-            }
-        }
+        decode_run_batch(wv, runs, rb, nb);
     }
 }
 
@@ -590,38 +847,39 @@ __global__ __launch_bounds__(VAL_WAVES * 64) void rlev2_values_kernel(
 
 hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                               const uint64_t *entries, uint32_t n_seg, int is_signed,
-                              SegCount *seg_count) {
-    const uint32_t blocks = (n_seg + 255) / 256;
-    rlev2_scan_kernel<false><<<blocks, 256, 0, st>>>(stream, len, entries, n_seg, is_signed,
-                                                    seg_count, nullptr, nullptr, nullptr, 0);
+                              const SegTable &t) {
+    const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
+    rlev2_scan_kernel<false><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, n_seg, is_signed, t,
+                                                          nullptr, nullptr, nullptr, 0);
     return hipGetLastError();
 }
 
-hipError_t launch_segment_scan(hipStream_t st, const SegCount *seg_count, uint32_t n_seg,
-                               uint64_t num_values, SegOffset *seg_off, ScanTotals *totals) {
-    segment_scan_kernel<<<1, SCAN_THREADS, 0, st>>>(seg_count, n_seg, num_values, seg_off, totals);
+hipError_t launch_block_totals_scan(hipStream_t st, const SegTable &t, uint32_t n_blocks,
+                                    uint64_t num_values) {
+    block_totals_scan_kernel<<<1, SCAN_THREADS, 0, st>>>(t, n_blocks, num_values);
     return hipGetLastError();
 }
 
 hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                              const uint64_t *entries, uint32_t n_seg, int is_signed,
-                             const SegCount *seg_count, const SegOffset *seg_off, RunEntry *runs,
-                             uint32_t *group_first, uint32_t n_group_slots) {
-    const uint32_t blocks = (n_seg + 255) / 256;
-    rlev2_scan_kernel<true><<<blocks, 256, 0, st>>>(stream, len, entries, n_seg, is_signed,
-                                                   const_cast<SegCount *>(seg_count), seg_off,
-                                                   runs, group_first, n_group_slots);
+                             const SegTable &t, RunEntry *runs, uint32_t *group_first,
+                             RunEntry *group_run, uint32_t n_group_slots) {
+    const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
+    rlev2_scan_kernel<true><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, n_seg, is_signed, t,
+                                                         runs, group_first, group_run,
+                                                         n_group_slots);
     return hipGetLastError();
 }
 
 hipError_t launch_rlev2_values(hipStream_t st, const uint8_t *stream, uint64_t len,
                                const RunEntry *runs, const uint32_t *group_first,
-                               uint32_t n_groups, uint32_t n_runs, uint64_t num_values,
-                               int is_signed, int64_t *out) {
+                               const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
+                               uint64_t num_values, int is_signed, int64_t *out) {
     if (n_groups == 0) return hipSuccess;
     const uint32_t blocks = (n_groups + VAL_WAVES - 1) / VAL_WAVES;
-    rlev2_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, runs, group_first, n_groups,
-                                                          n_runs, num_values, is_signed, out);
+    rlev2_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, runs, group_first, group_run,
+                                                          n_groups, n_runs, num_values, is_signed,
+                                                          out);
     return hipGetLastError();
 }
 

@@ -1,0 +1,136 @@
+// Prefix sums over the segments of a run-length stream (device code shared by the RLE v2 and
+// byte-RLE header scans).
+//
+// A segment is the stretch of headers between two entry points, walked by one lane.  The counting
+// kernels run 256 lanes per workgroup and finish with a workgroup-local scan (seg_publish); one
+// small kernel then scans the per-workgroup totals; the emitting kernels add the two levels back
+// together (seg_global_offset).
+#pragma once
+
+#include "orcd_internal.h"
+
+namespace orcd {
+
+constexpr int SEG_BLOCK = 256;  // lanes (= segments) per workgroup of the count and emit kernels
+
+struct BlockTotals {
+    uint64_t n_vals;
+    uint32_t n_runs;
+    uint32_t last_len;        // length of the last run in the workgroup's segments (0: no run)
+    uint64_t bad_local_end;   // values of the workgroup up to the end of its first stopped walk
+    uint32_t bad_seg;         // that segment, or 0xFFFFFFFF
+    uint32_t bad_status;
+};
+
+struct BlockOffset {
+    uint64_t val_off;
+    uint32_t run_off;
+    uint32_t prev_len;
+};
+
+struct SegTable {
+    SegCount *seg_count;    // [n_seg]
+    SegOffset *seg_local;   // [n_seg]   workgroup-local exclusive offsets
+    BlockTotals *blk;       // [n_blocks]
+    BlockOffset *boff;      // [n_blocks]
+    ScanTotals *totals;
+};
+
+__device__ __forceinline__ uint64_t seg_shfl_up64(uint64_t v, unsigned d) {
+    const uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Called by every lane of a SEG_BLOCK-wide counting workgroup, valid or not (`seg < n_seg`), with
+// the result of its walk.
+__device__ __forceinline__ void seg_publish(const SegTable &t, uint32_t seg, uint32_t n_seg,
+                                            uint32_t n_runs, uint32_t last_len, uint32_t status,
+                                            uint64_t n_vals) {
+    __shared__ uint64_t w_vals[SEG_BLOCK / 64];
+    __shared__ uint64_t w_key[SEG_BLOCK / 64];
+    __shared__ uint32_t w_runs[SEG_BLOCK / 64];
+    __shared__ uint32_t first_bad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool valid = seg < n_seg;
+    if (!valid) { n_runs = 0; last_len = 0; status = SEG_OK; n_vals = 0; }
+    if (threadIdx.x == 0) first_bad = 0xFFFFFFFFu;
+
+    // inclusive scans inside the wavefront: values, runs, and "most recent non-empty segment"
+    // as a running maximum over (lane + 1, last_len)
+    uint64_t iv = n_vals;
+    uint32_t ir = n_runs;
+    uint64_t ik = n_runs ? (((uint64_t)threadIdx.x + 1) << 10) | last_len : 0;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t uv = seg_shfl_up64(iv, d);
+        const uint32_t ur = __shfl_up(ir, d);
+        const uint64_t uk = seg_shfl_up64(ik, d);
+        if (lane >= d) {
+            iv += uv;
+            ir += ur;
+            ik = ik > uk ? ik : uk;
+        }
+    }
+    if (lane == 63) { w_vals[wave] = iv; w_runs[wave] = ir; w_key[wave] = ik; }
+    __syncthreads();
+    uint64_t pv = 0, pk = 0, tv = 0, tk = 0;
+    uint32_t pr = 0, tr = 0;
+    for (int w = 0; w < SEG_BLOCK / 64; w++) {
+        if (w < wave) { pv += w_vals[w]; pr += w_runs[w]; pk = pk > w_key[w] ? pk : w_key[w]; }
+        tv += w_vals[w];
+        tr += w_runs[w];
+        tk = tk > w_key[w] ? tk : w_key[w];
+    }
+    const uint64_t incl_key = ik > pk ? ik : pk;
+    // exclusive value of the key scan: the inclusive value of the previous lane
+    uint64_t excl_key = seg_shfl_up64(incl_key, 1);
+    if (lane == 0) excl_key = pk;
+    const uint64_t val_off = pv + iv - n_vals;
+    if (valid) {
+        SegCount c;
+        c.n_runs = n_runs;
+        c.last_len = last_len;
+        c.status = status;
+        c.pad = 0;
+        c.n_vals = n_vals;
+        t.seg_count[seg] = c;
+        SegOffset o;
+        o.val_off = val_off;
+        o.run_off = pr + ir - n_runs;
+        o.prev_len = (uint32_t)(excl_key & 1023);
+        t.seg_local[seg] = o;
+        if (status != SEG_OK) atomicMin(&first_bad, threadIdx.x);
+    }
+    __syncthreads();
+    const uint32_t fb = first_bad;
+    if (fb != 0xFFFFFFFFu && threadIdx.x == fb) {
+        t.blk[blockIdx.x].bad_local_end = val_off + n_vals;
+        t.blk[blockIdx.x].bad_seg = seg;
+        t.blk[blockIdx.x].bad_status = status;
+    }
+    if (threadIdx.x == 0) {
+        t.blk[blockIdx.x].n_vals = tv;
+        t.blk[blockIdx.x].n_runs = tr;
+        t.blk[blockIdx.x].last_len = (uint32_t)(tk & 1023);
+        if (fb == 0xFFFFFFFFu) {
+            t.blk[blockIdx.x].bad_local_end = 0;
+            t.blk[blockIdx.x].bad_seg = 0xFFFFFFFFu;
+            t.blk[blockIdx.x].bad_status = SEG_OK;
+        }
+    }
+}
+
+// Global exclusive offsets of a segment, for the emitting kernels (same SEG_BLOCK geometry).
+__device__ __forceinline__ SegOffset seg_global_offset(const SegTable &t, uint32_t seg) {
+    const SegOffset l = t.seg_local[seg];
+    const BlockOffset b = t.boff[seg / SEG_BLOCK];
+    SegOffset o;
+    o.val_off = b.val_off + l.val_off;
+    o.run_off = b.run_off + l.run_off;
+    o.prev_len = l.prev_len ? l.prev_len : b.prev_len;
+    return o;
+}
+
+hipError_t launch_block_totals_scan(hipStream_t st, const SegTable &t, uint32_t n_blocks,
+                                    uint64_t num_values);
+
+}  // namespace orcd

@@ -1,4 +1,5 @@
-"""Ad-hoc GPU debugging helper (not collected by pytest)."""
+"""Ad-hoc GPU debugging helper (not collected by pytest): decodes random streams restricted to
+subsets of run kinds and prints where the HIP decoder first departs from the oracle."""
 import sys
 
 import numpy as np
@@ -10,43 +11,35 @@ import rle_encode as enc  # noqa: E402
 from gpu_backend import GpuBackend  # noqa: E402
 
 
-def nbad(gpu, stream, expect, signed):
-    rc, out, _ = gpu.rlev2(stream, expect.size, signed)
-    assert rc == 0
-    bad = np.nonzero(out != expect)[0]
-    return bad, out
-
-
 def main():
     oracle = oracle_ctypes.load()
     gpu = GpuBackend()
-    rng = np.random.default_rng(3)
-    stream, expect, starts = enc.random_stream(rng, 50, False, max_len=512)
-    bad, _ = nbad(gpu, stream, expect, False)
-    print("fresh: bad", bad.size)
-    # poison the arena the way the test sequence does
-    for seed, n_runs, max_len in [(1, 300, 512), (2, 2000, 12)]:
-        r2 = np.random.default_rng(seed)
-        s2, e2, st2 = enc.random_stream(r2, n_runs, True, max_len=max_len)
-        b2, _ = nbad(gpu, s2, e2, True)
-        print("seed", seed, "bad", b2.size)
-        bad, _ = nbad(gpu, stream, expect, False)
-        print("  then seed-3 stream: bad", bad.size, bad[:6])
-    rc, runs_gpu = gpu.runs(stream, expect.size)
-    rc, runs_cpu = oracle.runs(stream, expect.size)
-    off = 0
-    for i, (g, c) in enumerate(zip(runs_gpu, runs_cpu)):
-        if i < 8 or g[3] != off:
-            print(i, "gpu kind/w/len/out/payload", g, "cpu kind/w/len/byte/bytes", c, "cpu out", off)
-        off += c[2]
-    # minimal failing prefix
-    rc, runs = oracle.runs(stream, expect.size)
-    offs = np.cumsum([0] + [r[2] for r in runs])
-    for k in range(1, 12):
-        end_byte = runs[k][3] if k < len(runs) else len(stream)
-        sub = stream[:end_byte]
-        bad, out = nbad(gpu, sub, expect[:offs[k]], False)
-        print("prefix", k, "runs:", "bad", bad.size, bad[:8])
+    cases = [((1,), 512), ((3,), 512), ((2,), 512), ((0,), 512), ((1, 3), 512), ((1, 2), 512),
+             ((0, 1, 2, 3), 512), ((0, 1, 2, 3), 40)]
+    for kinds, max_len in cases:
+        for seed in (1, 2, 3, 4):
+            for signed in (False, True):
+                rng = np.random.default_rng(seed)
+                stream, expect, starts = enc.random_stream(rng, 300, signed, kinds=kinds, max_len=max_len)
+                rc, out, _ = gpu.rlev2(stream, expect.size, signed)
+                if rc != 0:
+                    print("kinds", kinds, "seed", seed, "signed", signed, "rc", rc)
+                    continue
+                bad = np.nonzero(out != expect)[0]
+                if bad.size == 0:
+                    continue
+                rc, runs = oracle.runs(stream, expect.size)
+                offs = np.cumsum([0] + [r[2] for r in runs])
+                print("kinds", kinds, "max_len", max_len, "seed", seed, "signed", signed,
+                      "bad", bad.size, "of", expect.size)
+                brk = np.nonzero(np.diff(bad) > 1)[0]
+                for r in np.split(bad, brk + 1)[:6]:
+                    b = int(r[0])
+                    ri = int(np.searchsorted(offs, b, side="right") - 1)
+                    k, w, l, bo, bl = runs[ri]
+                    print("   range", b, "..", int(r[-1]), "run", ri, "kind", k, "w", w, "len", l,
+                          "out_off", int(offs[ri]), "pos", int(b - offs[ri]), "got",
+                          hex(int(out[b]) & (2**64 - 1)), "exp", hex(int(expect[b]) & (2**64 - 1)))
 
 
 if __name__ == "__main__":
