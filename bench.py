@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="values per GPU per step")
     ap.add_argument("--workload", default="direct_w17", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="also measure host -> device -> decode -> host (reported separately)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target duration of the CPU baseline sample")
     args = ap.parse_args()
@@ -99,10 +101,8 @@ def main():
             phase_ms[p] += ctx.phase_ms(p)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from orc_format_amd import shard
+    elapsed = shard.max_over_ranks(elapsed, dist, device="cuda")
 
     # parity of what was just timed: the decoded column equals the generator's values
     if not torch.equal(out, expect):
@@ -143,6 +143,23 @@ def main():
         "in_plus_out_GBps": round((decoded_bytes + stream_bytes) * args.steps * world / elapsed / 1e9, 2),
     }
 
+    # HBM bytes per launch of the value kernel come from PMC counters, which cannot be read from
+    # inside this process: they are taken from the newest committed rocprofv3 summary of this same
+    # command and workload (separate FETCH_SIZE / WRITE_SIZE passes, see profiles/README.md).
+    if rows == 1_000_000_000 - 1_000_000_000 % 512:
+        import glob
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_%s_traffic.json" % args.workload)))
+        if found:
+            with open(found[-1]) as f:
+                prof = json.load(f)
+            k = prof.get("kernels", {}).get("orcd::rlev2_values_kernel")
+            if k:
+                result["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = os.path.relpath(found[-1], ROOT)
+
+    if args.end_to_end:
+        result["end_to_end"] = end_to_end(args, ctx, stream, entries, expect, rows, signed, torch)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, stream, rows, stream_bytes, signed, expect, np)
     if rank == 0:
@@ -150,6 +167,41 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def end_to_end(args, ctx, stream, entries, expect, rows, signed, torch):
+    """Rate of the same decode when the stream starts in (pinned) host memory and the decoded
+    column ends there: H2D copy + decode + D2H copy on one HIP stream, no overlap.  Not the
+    headline value -- PCIe, not HBM, bounds it."""
+    n = min(rows, 256 * 1024 * 1024)
+    n_runs = n // 512
+    n = n_runs * 512
+    sbytes = int(stream.numel() * (n / rows))
+    h_stream = torch.empty(sbytes, dtype=torch.uint8).pin_memory()
+    h_stream.copy_(stream[:sbytes])
+    h_out = torch.empty(n, dtype=torch.int64).pin_memory()
+    d_stream = torch.empty(sbytes, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty(n, dtype=torch.int64, device="cuda")
+    n_entries = (n_runs + 19) // 20
+    side = torch.cuda.Stream()  # copies and kernels share this (non-default) stream
+    ctx.set_stream(side.cuda_stream)
+    times = []
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d_stream.copy_(h_stream, non_blocking=True)
+            ctx.rlev2_device(d_stream.data_ptr(), sbytes, n, signed, d_out.data_ptr(),
+                             entries.data_ptr(), n_entries)
+            h_out.copy_(d_out, non_blocking=True)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    ctx.set_stream(None)
+    assert torch.equal(h_out, expect[:n].cpu())
+    best = min(times)
+    return {"decoded_GBps": round(n * 8 / best / 1e9, 2), "rows": n, "seconds": round(best, 4),
+            "host_to_device_bytes": sbytes, "device_to_host_bytes": n * 8,
+            "note": "pinned host buffers, H2D + decode + D2H serialized on one stream"}
 
 
 def cpu_baseline(args, stream, rows, stream_bytes, signed, expect, np):

@@ -108,10 +108,10 @@ __device__ __forceinline__ bool parse_varint(const Window16 &w, const uint8_t *s
     return false;
 }
 
-// Parses the run whose header starts at `pos` (pos < len).  Returns a SEG_* status.
-__device__ __forceinline__ uint32_t parse_run(const uint8_t *s, uint64_t len, uint64_t pos,
-                                              int is_signed, ParsedRun &r) {
-    const Window16 w = load_window(s, len, pos);
+// Parses the run whose header starts at `pos` (pos < len) from its 16-byte window.  Returns a
+// SEG_* status.
+__device__ __forceinline__ uint32_t parse_run(const Window16 &w, const uint8_t *s, uint64_t len,
+                                              uint64_t pos, int is_signed, ParsedRun &r) {
     const uint32_t h0 = w.byte(0), h1 = w.byte(1);
     r.kind = h0 >> 6;
     r.base = 0;
@@ -168,6 +168,46 @@ __device__ __forceinline__ uint32_t parse_run(const uint8_t *s, uint64_t len, ui
     return SEG_OK;
 }
 
+// Walks the run headers of [pos, end), at most max_runs of them, calling consume(run) for each.
+// Headers form a serial chain -- a header's position is known only once its predecessor is
+// parsed -- so a plain walk pays one memory round trip per run.  Every round here loads the header
+// at `pos` together with three more at pos + k * (size of the previous run) and then parses as
+// many of the four as the chain confirms: in a long column most neighbouring runs have the same
+// size, and four headers then cost one round trip.  A wrong guess only costs the extra loads.
+template <typename Consume>
+__device__ __forceinline__ uint32_t walk_headers(const uint8_t *s, uint64_t len, uint64_t &pos,
+                                                 uint64_t end, uint32_t max_runs, int is_signed,
+                                                 Consume &&consume) {
+    uint64_t stride = 0;
+    uint32_t n = 0, status = SEG_OK;
+    ParsedRun r;
+    auto step = [&](const Window16 &w) -> bool {
+        status = parse_run(w, s, len, pos, is_signed, r);
+        if (status != SEG_OK) return false;
+        consume(r);
+        stride = r.run_end - pos;
+        pos = r.run_end;
+        n++;
+        return true;
+    };
+    while (pos < end && n < max_runs) {
+        const uint64_t p1 = pos + stride, p2 = p1 + stride, p3 = p2 + stride;
+        const bool h1 = stride != 0 && p1 < end, h2 = h1 && p2 < end, h3 = h2 && p3 < end;
+        const Window16 w0 = load_window(s, len, pos);
+        const Window16 w1 = load_window(s, len, h1 ? p1 : pos);
+        const Window16 w2 = load_window(s, len, h2 ? p2 : pos);
+        const Window16 w3 = load_window(s, len, h3 ? p3 : pos);
+        if (!step(w0)) break;
+        if (!(h1 && pos == p1 && n < max_runs)) continue;
+        if (!step(w1)) break;
+        if (!(h2 && pos == p2 && n < max_runs)) continue;
+        if (!step(w2)) break;
+        if (!(h3 && pos == p3 && n < max_runs)) continue;
+        if (!step(w3)) break;
+    }
+    return status;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: header scan -- one lane per segment.  COUNT pass: runs and values per segment, finished by
 // a workgroup-local prefix sum.  EMIT pass (after the scan of the workgroup totals): the run
@@ -192,14 +232,12 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
         uint32_t n_runs = 0, last_len = 0, status = SEG_OK;
         uint64_t n_vals = 0;
         if (end > len || end < pos) status = SEG_MISALIGNED;
-        while (valid && status == SEG_OK && pos < end) {
-            ParsedRun r;
-            status = parse_run(s, len, pos, is_signed, r);
-            if (status != SEG_OK) break;
-            n_runs++;
-            n_vals += r.len;
-            last_len = r.len;
-            pos = r.run_end;
+        if (valid && status == SEG_OK) {
+            status = walk_headers(s, len, pos, end, 0xFFFFFFFFu, is_signed, [&](const ParsedRun &r) {
+                n_runs++;
+                n_vals += r.len;
+                last_len = r.len;
+            });
         }
         if (status == SEG_OK && pos != end && !last_seg) status = SEG_MISALIGNED;
         seg_publish(t, seg, n_seg, n_runs, last_len, status, n_vals);
@@ -210,9 +248,8 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
         uint64_t out_off = so.val_off;
         uint32_t run_idx = so.run_off;
         uint32_t prev_len = so.prev_len;  // 0 only before the very first run
-        for (uint32_t k = 0; k < n_runs; k++) {
-            ParsedRun r;
-            parse_run(s, len, pos, is_signed, r);  // status was SEG_OK in the counting pass
+        // the counting pass found n_runs well-formed runs from here
+        walk_headers(s, len, pos, end, n_runs, is_signed, [&](const ParsedRun &r) {
             RunEntry e;
             e.desc = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg);
             e.out_off = out_off;
@@ -233,8 +270,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
             out_off += r.len;
             prev_len = r.len;
             run_idx++;
-            pos = r.run_end;
-        }
+        });
         if (last_seg) {
             // sentinel: one-past-the-end run and the window after the last value
             RunEntry e;

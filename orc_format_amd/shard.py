@@ -1,0 +1,57 @@
+"""Stripe sharding across the GPUs of one node.
+
+Stripes are self-contained (own footer, streams and row count -- reference: src/read/mod.rs:95-159,
+src/proto.rs:206-217), so every rank decodes a disjoint subset of them and nothing is exchanged on
+the data path.  torch.distributed (RCCL on GPUs, gloo on CPUs) is used only to agree on timing.
+"""
+import heapq
+
+
+def assign_stripes(data_lengths, world_size):
+    """Longest-processing-time-first assignment of stripes to ranks by data length.
+    Returns a list (one per rank) of ascending stripe indices; every stripe appears once."""
+    if world_size <= 0:
+        raise ValueError("world_size must be positive")
+    loads = [(0, r) for r in range(world_size)]
+    heapq.heapify(loads)
+    out = [[] for _ in range(world_size)]
+    for idx in sorted(range(len(data_lengths)), key=lambda i: (-data_lengths[i], i)):
+        load, r = heapq.heappop(loads)
+        out[r].append(idx)
+        heapq.heappush(loads, (load + data_lengths[idx], r))
+    return [sorted(x) for x in out]
+
+
+def row_offsets(rows_per_stripe):
+    """First row of every stripe: exclusive prefix sum of the stripes' row counts."""
+    out, acc = [], 0
+    for n in rows_per_stripe:
+        out.append(acc)
+        acc += n
+    return out
+
+
+def stripes_of_rank(metadata, rank, world_size):
+    """The stripes of an open file (read.FileMetadata) that `rank` decodes."""
+    lengths = [s.data_length for s in metadata.stripes]
+    return assign_stripes(lengths, world_size)[rank]
+
+
+def max_over_ranks(value, dist=None, device=None):
+    """Maximum of a float over all ranks (the job's elapsed time); a no-op without a process
+    group."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, dist=None, device=None):
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

@@ -336,3 +336,49 @@ def test_device_pointers_and_properties():
     ctx.synchronize()
     got = d_out.cpu().numpy()
     assert (np.diff(got) > 0).all() and got[-1] == t[-1] and (got == t).all()
+
+
+def test_deserialize_module(golden_dir, expected):
+    """orc_format_amd.deserialize: the reference harness's functions (deserialize.rs) over the
+    library's own host reader, ROW_INDEX entry points included; checked against pyarrow."""
+    orc = pytest.importorskip("pyarrow.orc")
+    from orc_format_amd import deserialize as de
+    from orc_format_amd import read
+    md = read.read_metadata(os.path.join(golden_dir, "test.orc"))
+    footer = read.read_stripe_footer(md, 0)
+    exp = expected["test.orc"]
+    v, x = de.deserialize_int_array(read.read_stripe_column(md, 0, footer, 15))
+    assert v.tolist() == exp["validity_15_17"] and x.tolist() == exp["15"]
+    v, x = de.deserialize_f32_array(read.read_stripe_column(md, 0, footer, 1))
+    assert v.tolist() == exp["validity_1_14"] and x.tolist() == exp["1"]
+    v, x = de.deserialize_bool_array(read.read_stripe_column(md, 0, footer, 2))
+    assert x.tolist() == exp["2"]
+    v, off, data = de.deserialize_str_array(read.read_stripe_column(md, 0, footer, 3))
+    assert de.strings(off, data) == exp["3"]
+    md = read.read_metadata(os.path.join(golden_dir, "string_dict.orc"))
+    footer = read.read_stripe_footer(md, 0)
+    v, off, data = de.deserialize_str_array(read.read_stripe_column(md, 0, footer, 1))
+    assert de.strings(off, data) == ["abc", "efgh"] * 32
+
+    path = os.path.join(golden_dir, "mixed_compression.orc")
+    table = orc.ORCFile(path).read()
+    md = read.read_metadata(path)
+    footer = read.read_stripe_footer(md, 0)
+    for ci, name in enumerate(table.column_names):
+        column = read.read_stripe_column(md, 0, footer, ci + 1)
+        want = table.column(name).to_pylist()
+        kind = md.types[ci + 1]
+        if kind in (2, 3, 4):
+            v, x = de.deserialize_int_array(column)
+            got = assemble.scatter(v, x)
+        elif kind == 6:
+            v, x = de.deserialize_f64_array(column)
+            assert x.tobytes() == np.array([w for w in want if w is not None]).tobytes()
+            continue
+        elif kind == 0:
+            v, x = de.deserialize_bool_array(column)
+            got = assemble.scatter(v, x)
+        else:
+            v, off, data = de.deserialize_str_array(column)
+            got = assemble.scatter(v, de.strings(off, data))
+        assert got == want, name

@@ -1,0 +1,89 @@
+"""The multi-GPU path on CPUs: world_size-2 gloo run of the stripe sharding used by bench.py and
+by multi-stripe files.  Each rank reads and decodes only its stripes (the CPU oracle stands in for
+the GPU decoder here); together the ranks must reproduce the whole column, with no exchange of
+column data between them."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from orc_format_amd import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_assign_stripes_is_a_balanced_partition():
+    lengths = [5, 9, 1, 7, 7, 3, 8, 2, 6, 4]
+    for world in (1, 2, 3, 8, 16):
+        parts = shard.assign_stripes(lengths, world)
+        assert len(parts) == world
+        assert sorted(i for p in parts for i in p) == list(range(len(lengths)))
+        loads = [sum(lengths[i] for i in p) for p in parts]
+        assert max(loads) - min(l for l in loads if l or world <= len(lengths)) <= max(lengths)
+    assert shard.assign_stripes([], 4) == [[], [], [], []]
+    assert shard.row_offsets([3, 4, 5]) == [0, 3, 7]
+    # equal stripes (the synthetic benchmark) spread evenly
+    parts = shard.assign_stripes([10] * 16, 8)
+    assert all(len(p) == 2 for p in parts)
+
+
+def _worker(rank, world, port, path, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    import oracle_ctypes
+    from orc_format_amd import read
+    from orc_format_amd.proto import StreamKind
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        oracle = oracle_ctypes.load()
+        md = read.read_metadata(path)
+        mine = shard.stripes_of_rank(md, rank, world)
+        rows = 0
+        decoded = {}
+        for s in mine:
+            footer = read.read_stripe_footer(md, s)
+            column = read.read_stripe_column(md, s, footer, 1)  # "w17": int64, no nulls
+            n = column.number_of_rows()
+            rc, vals, _ = oracle.rlev2(bytes(column.get_stream(StreamKind.Data)), n, True)
+            assert rc == 0
+            decoded[s] = vals
+            rows += n
+        total_rows = shard.sum_over_ranks(rows, dist)
+        slowest = shard.max_over_ranks(float(rank + 1), dist)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)  # control plane only: which stripes, not the data
+        results[rank] = (mine, decoded, total_rows, slowest, gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo(golden_dir, tmp_path):
+    mp = pytest.importorskip("torch.multiprocessing")
+    pa_orc = pytest.importorskip("pyarrow.orc")
+    path = os.path.join(golden_dir, "mixed_speed.orc")
+    world = 2
+    manager = mp.Manager()
+    results = manager.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, path, results), nprocs=world, join=True)
+    assert sorted(results.keys()) == [0, 1]
+    table = pa_orc.ORCFile(path).read()
+    expect = np.array(table.column("w17").to_pylist(), dtype=np.int64)
+    all_stripes = sorted(s for r in range(world) for s in results[r][0])
+    n_stripes = len(all_stripes)
+    assert all_stripes == list(range(n_stripes)) and n_stripes > 2
+    assert not set(results[0][0]) & set(results[1][0])
+    for r in range(world):
+        assert results[r][2] == len(expect)          # rows summed over ranks
+        assert results[r][3] == float(world)         # max over ranks
+        assert results[r][4] == [results[0][0], results[1][0]]
+    merged = {}
+    for r in range(world):
+        merged.update(results[r][1])
+    got = np.concatenate([merged[s] for s in range(n_stripes)])
+    assert (got == expect).all()
