@@ -170,6 +170,69 @@ __global__ __launch_bounds__(WAVES * 64) void lab_pipelined(const uint8_t *__res
     }
 }
 
+
+// WPW windows per wavefront: all loads first, then decode and store each window.
+// NT: nontemporal stores.  XCD: remap workgroups so that each XCD (workgroup id mod 8) walks one
+// contiguous eighth of the column.
+template <int WAVES, int WPW, bool NT, bool XCD>
+__global__ __launch_bounds__(WAVES * 64) void lab_multi(const uint8_t *__restrict__ s,
+                                                       const Entry *__restrict__ tab,
+                                                       uint32_t n_runs, int64_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[WAVES][WPW][1088 / 4 + 8 + 4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t b = blockIdx.x;
+    if (XCD) {
+        const uint32_t nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8, i = b / 8;
+        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const uint32_t g0 = (b * WAVES + wave) * WPW;
+    uint32_t skews[WPW];
+    uint64_t outs[WPW];
+#pragma unroll
+    for (int k = 0; k < WPW; k++) {
+        const uint32_t g = g0 + k;
+        skews[k] = 0;
+        outs[k] = 0;
+        if (g >= n_runs) continue;
+        const Entry e = tab[g];
+        const uint64_t payload = __builtin_amdgcn_readfirstlane((uint32_t)e.payload) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(e.payload >> 32)) << 32);
+        outs[k] = __builtin_amdgcn_readfirstlane((uint32_t)e.out_off) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(e.out_off >> 32)) << 32);
+        const uint32_t skew = (uint32_t)((uintptr_t)(s + payload) & 15);
+        skews[k] = skew;
+        const uint4 *src = (const uint4 *)(s + payload - skew);
+        const uint32_t n16 = (1088 + skew + 15) >> 4;
+        for (uint32_t c = lane; c < n16; c += 64) {
+            uint4 v = src[c];
+            v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y);
+            v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+            ((uint4 *)stage[wave][k])[c] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < WPW; k++) {
+        if (g0 + k >= n_runs) continue;
+        const uint32_t *lds = stage[wave][k];
+        const uint32_t bit0 = skews[k] * 8;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t i0 = 128 * j + 2 * lane;
+            const uint32_t m0 = lds_bits32(lds, bit0 + i0 * 17, 17), m1 = lds_bits32(lds, bit0 + (i0 + 1) * 17, 17);
+            const uint64_t v0 = (uint64_t)(int64_t)(int32_t)((m0 >> 1) ^ (0u - (m0 & 1u)));
+            const uint64_t v1 = (uint64_t)(int64_t)(int32_t)((m1 >> 1) ^ (0u - (m1 & 1u)));
+            int64_t *dst = out + outs[k] + i0;
+            if (NT) {
+                __builtin_nontemporal_store((int64_t)v0, dst);
+                __builtin_nontemporal_store((int64_t)v1, dst + 1);
+            } else {
+                *(ulonglong2 *)dst = make_ulonglong2(v0, v1);
+            }
+        }
+    }
+}
+
 template <typename F>
 float time_ms(F launch, int reps = 5) {
     hipEvent_t a, b;
@@ -224,7 +287,19 @@ int main(int argc, char **argv) {
     RUN1(15, "entry + stage + decode + store (full)", true);
     RUN1(7, "entry + stage + decode, no store", false);
     RUN1(14, "no entry: stage + decode + store", true);
-    for (int bpc : {4, 8, 12, 16}) {
+#define RUNM(WAVES, WPW, NT, XCD, NAME) report(NAME, time_ms([&] { lab_multi<WAVES, WPW, NT, XCD><<<(n_runs + WAVES * WPW - 1) / (WAVES * WPW), WAVES * 64>>>(s, tab, n_runs, out); }), true)
+    RUNM(4, 1, false, false, "multi: 4 waves x 1 window");
+    RUNM(4, 1, true, false, "multi: 4 waves x 1 window, nontemporal");
+    RUNM(4, 1, false, true, "multi: 4 waves x 1 window, XCD remap");
+    RUNM(4, 2, false, false, "multi: 4 waves x 2 windows");
+    RUNM(4, 2, false, true, "multi: 4 waves x 2 windows, XCD remap");
+    RUNM(4, 4, false, false, "multi: 4 waves x 4 windows");
+    RUNM(8, 1, false, false, "multi: 8 waves x 1 window");
+    RUNM(8, 2, false, false, "multi: 8 waves x 2 windows");
+    RUNM(2, 1, false, false, "multi: 2 waves x 1 window");
+    RUNM(1, 1, false, false, "multi: 1 wave x 1 window");
+    RUNM(16, 1, false, false, "multi: 16 waves x 1 window");
+    for (int bpc : {8}) {
         char name[96];
         const uint32_t pb = 256 * bpc;
         snprintf(name, sizeof name, "persistent full, %d blocks/CU x4 waves", bpc);

@@ -460,15 +460,28 @@ __device__ __forceinline__ void payload_range(uint32_t kind, uint32_t w, uint32_
     b1 = ((uint64_t)last * w + 7) >> 3;
 }
 
+// The decoded column is written once and not read back by this kernel: nontemporal stores keep
+// it from displacing the stream bytes and run tables in L2.
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stream_store2(int64_t *dst, uint64_t v0, uint64_t v1) {
+    u64x2 v;
+    v.x = v0;
+    v.y = v1;
+    __builtin_nontemporal_store(v, (u64x2 *)dst);
+}
+__device__ __forceinline__ void stream_store1(int64_t *dst, uint64_t v) {
+    __builtin_nontemporal_store((int64_t)v, dst);
+}
+
 // Two adjacent output values of one lane.
 __device__ __forceinline__ void store_pair(const Wave &wv, uint64_t e0, uint64_t v0, uint64_t v1,
                                            bool a0, bool a1) {
     int64_t *dst = wv.out + e0;
     if (a0 && a1 && wv.out_aligned) {
-        *(ulonglong2 *)dst = make_ulonglong2(v0, v1);
+        stream_store2(dst, v0, v1);
     } else {
-        if (a0) dst[0] = (int64_t)v0;
-        if (a1) dst[1] = (int64_t)v1;
+        if (a0) stream_store1(dst, v0);
+        if (a1) stream_store1(dst + 1, v1);
     }
 }
 
@@ -511,7 +524,7 @@ __device__ __forceinline__ void apply_patches(const Wave &wv, uint64_t desc, uin
     if ((uint32_t)wv.lane < pll && !filler && posn < rlen && run_out + posn < wv.num_values) {
         uint64_t m = global_bits(words, (uint64_t)sk * 8 + (uint64_t)posn * w, w);
         if (w < 64) m |= patch << w;
-        wv.out[run_out + posn] = (int64_t)(base + m);
+        stream_store1(wv.out + run_out + posn, base + m);
     }
 }
 
@@ -526,15 +539,15 @@ __device__ __forceinline__ void store_window_pair(const Wave &wv, int64_t *wout,
                                                   uint64_t v0, uint64_t v1, uint32_t lo_rel,
                                                   uint32_t hi_rel) {
     if (FULL) {
-        *(ulonglong2 *)(wout + i_rel) = make_ulonglong2(v0, v1);
+        stream_store2(wout + i_rel, v0, v1);
     } else {
         const bool a0 = i_rel >= lo_rel && i_rel < hi_rel;
         const bool a1 = i_rel + 1 >= lo_rel && i_rel + 1 < hi_rel;
         if (a0 && a1 && wv.out_aligned) {
-            *(ulonglong2 *)(wout + i_rel) = make_ulonglong2(v0, v1);
+            stream_store2(wout + i_rel, v0, v1);
         } else {
-            if (a0) wout[i_rel] = (int64_t)v0;
-            if (a1) wout[i_rel + 1] = (int64_t)v1;
+            if (a0) stream_store1(wout + i_rel, v0);
+            if (a1) stream_store1(wout + i_rel + 1, v1);
         }
     }
 }
@@ -844,7 +857,15 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
     int64_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[VAL_WAVES][STAGE_WORDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t g = blockIdx.x * VAL_WAVES + wave;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own: remap the
+    // workgroup id so that workgroups sharing an XCD (equal id mod 8) walk one contiguous eighth
+    // of the column, and a stream line straddling two neighbouring groups is fetched into one L2.
+    uint32_t wg = blockIdx.x;
+    {
+        const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = wg % 8;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
+    }
+    const uint32_t g = wg * VAL_WAVES + wave;
     if (g >= n_groups) return;  // whole wavefront leaves; no workgroup barrier is used below
     Wave wv;
     wv.s = s;
