@@ -585,9 +585,42 @@ __device__ __forceinline__ void direct_window(const Wave &wv, int64_t *wout, uin
     }
 }
 
-// Delta values of one window: value[i] = base (+ delta_base for i >= 1) +/- the packed deltas up
-// to i.  idx0: index in the run of this lane's first value of step 0 (negative before the run).
-template <bool FULL, bool WIDE>
+// Inclusive prefix sums over the 64 lanes with DPP row shifts and row broadcasts (no LDS traffic):
+// shifts by 1, 2, 4, 8 scan each row of 16 lanes, then lane 15 of rows 0 and 2 is added to rows 1
+// and 3, then lane 31 to rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v) {
+    v += dpp_or_zero<0x111, 0xF>(v);
+    v += dpp_or_zero<0x112, 0xF>(v);
+    v += dpp_or_zero<0x114, 0xF>(v);
+    v += dpp_or_zero<0x118, 0xF>(v);
+    v += dpp_or_zero<0x142, 0xA>(v);
+    v += dpp_or_zero<0x143, 0xC>(v);
+    return v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_or_zero64(uint64_t v) {
+    return ((uint64_t)dpp_or_zero<CTRL, ROW_MASK>((uint32_t)(v >> 32)) << 32) |
+           dpp_or_zero<CTRL, ROW_MASK>((uint32_t)v);
+}
+__device__ __forceinline__ uint64_t wave_scan_dpp(uint64_t v) {
+    v += dpp_or_zero64<0x111, 0xF>(v);
+    v += dpp_or_zero64<0x112, 0xF>(v);
+    v += dpp_or_zero64<0x114, 0xF>(v);
+    v += dpp_or_zero64<0x118, 0xF>(v);
+    v += dpp_or_zero64<0x142, 0xA>(v);
+    v += dpp_or_zero64<0x143, 0xC>(v);
+    return v;
+}
+
+// Delta values of one window: value[i] = base (+ delta_base for i >= 1) +/- the sum of the packed
+// deltas up to i.  Only the packed magnitudes are scanned; SUM is uint32_t when 510 of them cannot
+// overflow 32 bits (width <= 23).  idx0: index in the run of this lane's first value of step 0
+// (negative before the run).  carry: sum of the run's magnitudes before the current step.
+template <bool FULL, bool WIDE, typename SUM>
 __device__ __forceinline__ void delta_window(const Wave &wv, int64_t *wout, uint32_t w, bool neg,
                                              uint64_t base, uint64_t delta_base, uint32_t bit_lane,
                                              int32_t idx0, uint32_t lo_rel, uint32_t hi_rel,
@@ -598,23 +631,24 @@ __device__ __forceinline__ void delta_window(const Wave &wv, int64_t *wout, uint
         const int32_t i0 = idx0 + 128 * j, i1 = i0 + 1;
         const bool a0 = FULL || (i_rel >= lo_rel && i_rel < hi_rel);
         const bool a1 = FULL || (i_rel + 1 >= lo_rel && i_rel + 1 < hi_rel);
-        const bool p0 = a0 && i0 >= 2, p1 = a1 && i1 >= 2;
+        const bool p0 = a0 && i0 >= 2, p1 = a1 && i1 >= 2;  // values that have a packed delta
         const uint32_t bA = p0 ? bit_lane + (128u * j) * w : 0u;
         const uint32_t bB = p1 ? bit_lane + (128u * j + 1) * w : 0u;
-        uint64_t m0, m1;
+        SUM m0, m1;
         if (!WIDE) {
-            m0 = lds_bits32(wv.lds, bA, w);
-            m1 = lds_bits32(wv.lds, bB, w);
+            m0 = (SUM)lds_bits32(wv.lds, bA, w);
+            m1 = (SUM)lds_bits32(wv.lds, bB, w);
         } else {
-            m0 = lds_bits64(wv.lds, bA, w);
-            m1 = lds_bits64(wv.lds, bB, w);
+            m0 = (SUM)lds_bits64(wv.lds, bA, w);
+            m1 = (SUM)lds_bits64(wv.lds, bB, w);
         }
-        // per-value step: base for the first value, delta_base for the second
-        const uint64_t c0 = p0 ? (neg ? 0 - m0 : m0) : (a0 ? (i0 == 0 ? base : delta_base) : 0);
-        const uint64_t c1 = p1 ? (neg ? 0 - m1 : m1) : (a1 ? (i1 == 0 ? base : delta_base) : 0);
-        const uint64_t v1 = carry + wave_scan_u64(c0 + c1, wv.lane);
-        const uint64_t v0 = v1 - c1;
-        carry = readlane64(v1, 63);
+        if (!p0) m0 = 0;
+        if (!p1) m1 = 0;
+        const SUM incl = wave_scan_dpp((SUM)(m0 + m1));  // magnitudes of this step up to value i1
+        const uint64_t s1 = carry + incl, s0 = s1 - m1;
+        const uint64_t f0 = i0 >= 1 ? base + delta_base : base, f1 = i1 >= 1 ? base + delta_base : base;
+        const uint64_t v0 = neg ? f0 - s0 : f0 + s0, v1 = neg ? f1 - s1 : f1 + s1;
+        carry = readlane64(s1, 63);
         store_window_pair<FULL>(wv, wout, i_rel, v0, v1, lo_rel, hi_rel);
     }
 }
@@ -639,7 +673,7 @@ __device__ __forceinline__ void decode_single_run(const Wave &wv, uint64_t desc,
     uint64_t run_end = run_out + rlen;
     if (run_end > wv.num_values) run_end = wv.num_values;
     const bool packed_kind = w != 0 && kind != KIND_SHORT_REPEAT;
-    uint64_t carry = 0;  // Delta: value of the element before the current step
+    uint64_t carry = 0;  // Delta: sum of the run's packed deltas before the current step
     for (uint64_t wbase = (run_out >> WINDOW_SHIFT) << WINDOW_SHIFT; wbase < run_end; wbase += WINDOW) {
         // active values of this window, relative to its start
         const uint32_t lo_rel = wbase > run_out ? 0u : (uint32_t)(run_out - wbase);
@@ -673,12 +707,15 @@ __device__ __forceinline__ void decode_single_run(const Wave &wv, uint64_t desc,
         } else if (kind == KIND_DELTA && w != 0) {
             const bool neg = desc_delta_neg(desc) != 0;
             const uint32_t bit_lane = bit0 + (uint32_t)(idx0 - 2) * w;
-            if (w <= 32) {
-                if (full) delta_window<true, false>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
-                else delta_window<false, false>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
+            if (w <= 23) {
+                if (full) delta_window<true, false, uint32_t>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
+                else delta_window<false, false, uint32_t>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
+            } else if (w <= 32) {
+                if (full) delta_window<true, false, uint64_t>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
+                else delta_window<false, false, uint64_t>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
             } else {
-                if (full) delta_window<true, true>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
-                else delta_window<false, true>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
+                if (full) delta_window<true, true, uint64_t>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
+                else delta_window<false, true, uint64_t>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
             }
         } else {
             const uint64_t step = kind == KIND_DELTA ? aux : 0;
