@@ -525,14 +525,20 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
         ORCD_TRY(rlev2_device(c, (const uint8_t *)d_len_stream, length_len, num_values,
                               (const uint64_t *)d_entries, n_length_entries, 0, d_offsets));
     }
-    void *sums;
+    if (data_len >= (1ull << 52)) return ORCD_INVALID_ARGUMENT;
+    void *sums, *over;
     ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(num_values) * sizeof(uint64_t), &sums));
-    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)d_offsets, num_values, (uint64_t *)sums));
+    ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &over));
+    HIP_TRY(c, hipMemsetAsync(over, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)d_offsets, num_values, (uint64_t *)sums,
+                                         data_len, (uint32_t *)over));
     HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_offsets + num_values, sizeof(uint64_t),
                               hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, over, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint64_t total = c->h_scalars[0];
-    if (total > data_len) return ORCD_OUT_OF_SPEC;  // Values::next would run out of bytes
+    // Values::next would run out of bytes (variable_length.rs:15-23): one length alone, or the sum
+    if (*(uint32_t *)(c->h_scalars + 1) || total > data_len) return ORCD_OUT_OF_SPEC;
     const uint8_t *d_data = data;
     uint8_t *d_bytes = bytes_out;
     const bool want_utf8 = (flags & ORCD_CHECK_UTF8) && total;
@@ -595,7 +601,7 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
     } else {
         dict_total = (size_t)dict_offsets[dict_size];
     }
-    if (dict_total && !dict_bytes) return ORCD_INVALID_ARGUMENT;
+    if ((dict_total && !dict_bytes) || dict_total >= (1ull << 52)) return ORCD_INVALID_ARGUMENT;
     ORCD_TRY(stage_in(c, SLOT_IN_B, dict_bytes, dict_total, in_dev, &d_dict_bytes));
     ORCD_TRY(stage_in(c, SLOT_IN_D, indices, num_values * sizeof(int64_t), in_dev, &d_idx));
     int64_t *d_offsets = offsets_out;
@@ -608,15 +614,20 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
     ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
     ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(num_values) * sizeof(uint64_t), &sums));
     HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
-    HIP_TRY(c, launch_dictionary_lengths(c->stream, (const int64_t *)d_dict_off, dict_size,
+    HIP_TRY(c, launch_dictionary_lengths(c->stream, (const int64_t *)d_dict_off, dict_size, dict_total,
                                          (const int64_t *)d_idx, num_values, (uint64_t *)d_offsets,
                                          (uint32_t *)flag));
-    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)d_offsets, num_values, (uint64_t *)sums));
+    // every length is <= dict_total here, so bit 0 cannot be raised by the scan
+    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)d_offsets, num_values, (uint64_t *)sums,
+                                         dict_total, (uint32_t *)flag));
     HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_offsets + num_values, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (*(uint32_t *)(c->h_scalars + 1)) return ORCD_OUT_OF_SPEC;
+    const uint32_t bad = *(uint32_t *)(c->h_scalars + 1);
+    if (bad & 2u) return ORCD_INVALID_ARGUMENT;  // dict_offsets do not describe dict_bytes
+    if (bad) return ORCD_OUT_OF_SPEC;
     const uint64_t total = c->h_scalars[0];
+    if (total == ~0ull) return ORCD_INVALID_ARGUMENT;  // the column would exceed 2^64 bytes
     uint8_t *d_bytes = bytes_out;
     if (bytes_out) {
         if (total > bytes_capacity) return ORCD_INVALID_ARGUMENT;

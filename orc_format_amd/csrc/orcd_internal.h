@@ -119,16 +119,19 @@ hipError_t launch_bool_expand(hipStream_t st, const uint8_t *packed, uint64_t nu
                               uint8_t *out_bytes, uint8_t *out_bitmap, uint64_t *set_bits);
 
 // In-place exclusive prefix sum of n 64-bit values; data[n] receives the total.
-// `block_sums` needs room for scan_block_sums_len(n) values.
+// `block_sums` needs room for scan_block_sums_len(n) values.  A value above `limit` (which must
+// be below 2^52) sets bit 0 of *over_flag; with every value within the limit the sums of a tile
+// cannot wrap, and the sums across tiles saturate at UINT64_MAX instead of wrapping, so a total
+// that is <= limit proves that every offset is exact and in [0, limit].
 size_t scan_block_sums_len(uint64_t n);
 hipError_t launch_exclusive_scan_u64(hipStream_t st, uint64_t *data, uint64_t n,
-                                     uint64_t *block_sums);
+                                     uint64_t *block_sums, uint64_t limit, uint32_t *over_flag);
 
 hipError_t launch_utf8_validate(hipStream_t st, const uint8_t *bytes, const int64_t *offsets,
                                 uint64_t n, uint32_t *invalid_flag, uint64_t total_bytes);
 hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
-                                     const int64_t *indices, uint64_t n, uint64_t *lengths_out,
-                                     uint32_t *error_flag);
+                                     uint64_t dict_total, const int64_t *indices, uint64_t n,
+                                     uint64_t *lengths_out, uint32_t *error_flag);
 hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
                                     const uint8_t *dict_bytes, const int64_t *indices, uint64_t n,
                                     const int64_t *offsets_out, uint8_t *bytes_out);

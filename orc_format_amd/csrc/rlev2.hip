@@ -387,6 +387,7 @@ constexpr uint32_t STAGE_WORDS = STAGE_BYTES / 4 + 4;  // + padding for the 3-wo
 
 struct Wave {
     const uint8_t *s;      // stream
+    uint64_t len;          // its length: no load of the kernel may start at or after s + len
     uint32_t *lds;         // this wavefront's staging slice
     int64_t *out;
     uint64_t num_values;
@@ -399,6 +400,11 @@ struct Wave {
 // stands for (up to 15 bytes before b0; it may wrap below zero, only differences are used).
 // Reads whole aligned 16-byte chunks: each holds at least one byte of [b0, b1).
 __device__ __forceinline__ uint64_t stage_bytes(const Wave &wv, uint64_t b0, uint64_t b1) {
+    // Belt and braces: the header scan has validated every run against the stream length, but a
+    // range that is out of the stream or larger than the slice is never loaded, whatever the
+    // tables say.
+    if (b1 > wv.len) b1 = wv.len;
+    if (b0 >= b1 || b1 - b0 > STAGE_BYTES) return b0;
     const uint32_t skew = (uint32_t)((uintptr_t)(wv.s + b0) & 15);
     const uint4 *src = (const uint4 *)(wv.s + b0 - skew);
     const uint32_t n16 = (uint32_t)((b1 - b0 + skew + 15) >> 4);
@@ -513,6 +519,9 @@ __device__ __forceinline__ void apply_patches(const Wave &wv, uint64_t desc, uin
     const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
     const uint32_t *words = (const uint32_t *)(p - sk);
     const uint64_t list_bit = (uint64_t)sk * 8 + (((uint64_t)w * rlen + 7) >> 3) * 8;
+    // never read past the stream, whatever the table says (the header scan has checked this)
+    if (desc_payload(desc) + (((uint64_t)w * rlen + 7) >> 3) + (((uint64_t)cfb * pll + 7) >> 3) > wv.len)
+        return;
     uint64_t gap = 0, patch = 0;
     if ((uint32_t)wv.lane < pll) {
         const uint64_t entry = global_bits(words, list_bit + (uint64_t)wv.lane * cfb, cfb);
@@ -521,7 +530,14 @@ __device__ __forceinline__ void apply_patches(const Wave &wv, uint64_t desc, uin
     }
     const uint32_t posn = wave_scan_u32((uint32_t)gap, wv.lane);  // position = sum of the gaps
     const bool filler = gap == 255 && patch == 0;                 // only extends the gap
-    if ((uint32_t)wv.lane < pll && !filler && posn < rlen && run_out + posn < wv.num_values) {
+    // A zero gap after the first entry points back at a position the sequential readers have
+    // already passed: they apply neither that entry nor any later one.
+    const bool prev_filler = __shfl_up((uint32_t)filler, 1) != 0;  // a filler moves the position on
+    const uint64_t stuck =
+        __ballot((uint32_t)wv.lane < pll && wv.lane >= 1 && gap == 0 && !prev_filler);
+    const bool reachable = (stuck & ((2ull << wv.lane) - 1)) == 0;
+    if ((uint32_t)wv.lane < pll && !filler && reachable && posn < rlen &&
+        run_out + posn < wv.num_values) {
         uint64_t m = global_bits(words, (uint64_t)sk * 8 + (uint64_t)posn * w, w);
         if (w < 64) m |= patch << w;
         stream_store1(wv.out + run_out + posn, base + m);
@@ -672,6 +688,7 @@ __device__ __forceinline__ void decode_single_run(const Wave &wv, uint64_t desc,
     const uint32_t kind = desc_kind(desc), w = desc_width(desc), rlen = desc_len(desc);
     uint64_t run_end = run_out + rlen;
     if (run_end > wv.num_values) run_end = wv.num_values;
+    if (run_out >= run_end) return;  // the run starts at or after the last wanted value
     const bool packed_kind = w != 0 && kind != KIND_SHORT_REPEAT;
     uint64_t carry = 0;  // Delta: sum of the run's packed deltas before the current step
     for (uint64_t wbase = (run_out >> WINDOW_SHIFT) << WINDOW_SHIFT; wbase < run_end; wbase += WINDOW) {
@@ -751,6 +768,7 @@ __device__ __forceinline__ void decode_run_batch(const Wave &wv, const RunEntry 
     const uint64_t batch_beg = readlane64(me.out_off, 0);
     uint64_t batch_end = readlane64(me.out_off + my_len, (int)nb - 1);
     if (batch_end > wv.num_values) batch_end = wv.num_values;
+    if (batch_beg >= batch_end) return;  // every run of the batch lies after the last wanted value
     const uint32_t my_rel = (uint32_t)lane < nb ? (uint32_t)(me.out_off - batch_beg) : 0xFFFFFFFFu;
     uint64_t carry = 0;  // running value of a Delta run that continues into the next step
 
@@ -836,9 +854,12 @@ __device__ __forceinline__ void decode_run_batch(const Wave &wv, const RunEntry 
                         const uint32_t bit = (uint32_t)((desc_payload(f.desc) - lds_origin) << 3) + fidx * w;
                         m = lds_bits64(wv.lds, bit, w);
                     } else {
-                        const uint8_t *p = wv.s + desc_payload(f.desc);
+                        const uint64_t pay = desc_payload(f.desc);
+                        const uint8_t *p = wv.s + pay;
                         const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
-                        m = global_bits((const uint32_t *)(p - sk), (uint64_t)sk * 8 + (uint64_t)fidx * w, w);
+                        m = 0;
+                        if (pay + (((uint64_t)fidx * w + w + 7) >> 3) <= wv.len)
+                            m = global_bits((const uint32_t *)(p - sk), (uint64_t)sk * 8 + (uint64_t)fidx * w, w);
                     }
                     if (kind == KIND_DIRECT) val = wv.is_signed ? zigzag(m) : m;
                     else if (kind == KIND_PATCHED_BASE) val = f.base + m;
@@ -909,6 +930,7 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
     wv.lds = stage[wave];
     wv.out = out;
     wv.num_values = num_values;
+    wv.len = len;
     wv.lane = threadIdx.x & 63;
     wv.is_signed = is_signed;
     wv.out_aligned = (((uintptr_t)out) & 15) == 0;

@@ -34,6 +34,20 @@ __device__ __forceinline__ uint64_t lane63_u64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+__device__ __forceinline__ uint64_t sat_add(uint64_t a, uint64_t b) {
+    const uint64_t s = a + b;
+    return s < a ? ~0ull : s;
+}
+
+// inclusive wave scan under saturating addition (associative on unsigned values)
+__device__ __forceinline__ uint64_t wave_inclusive_sat_sum(uint64_t v, int lane) {
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
+        if (lane >= d) v = sat_add(v, ((uint64_t)hi << 32) | lo);
+    }
+    return v;
+}
+
 __device__ __forceinline__ uint64_t wave_inclusive_sum(uint64_t v, int lane) {
     for (int d = 1; d < 64; d <<= 1) {
         uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
@@ -43,21 +57,26 @@ __device__ __forceinline__ uint64_t wave_inclusive_sum(uint64_t v, int lane) {
 }
 
 __global__ __launch_bounds__(SCAN_WAVES * 64) void scan_reduce_kernel(
-    const uint64_t *__restrict__ data, uint64_t n, uint64_t *__restrict__ tile_sums) {
+    const uint64_t *__restrict__ data, uint64_t n, uint64_t *__restrict__ tile_sums,
+    uint64_t limit, uint32_t *__restrict__ over_flag) {
     __shared__ uint64_t wsum[SCAN_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t)blockIdx.x * TILE_ITEMS + (uint64_t)wave * WAVE_ITEMS;
-    uint64_t acc = 0;
+    uint64_t acc = 0, biggest = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS_PER_LANE / 2; j++) {
         const uint64_t i = base + 128u * j + 2u * lane;
         if (i + 1 < n) {
             const ulonglong2 v = *(const ulonglong2 *)(data + i);
             acc += v.x + v.y;
+            biggest = max(biggest, max(v.x, v.y));
         } else if (i < n) {
-            acc += data[i];
+            const uint64_t x = data[i];
+            acc += x;
+            biggest = max(biggest, x);
         }
     }
+    if (biggest > limit) atomicOr(over_flag, 1u);
     acc = wave_sum(acc);
     if (lane == 0) wsum[wave] = acc;
     __syncthreads();
@@ -68,7 +87,8 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void scan_reduce_kernel(
     }
 }
 
-// exclusive scan of the tile sums by one workgroup; tile_sums[n_tiles] receives the grand total
+// exclusive scan of the tile sums by one workgroup; tile_sums[n_tiles] receives the grand total.
+// Sums saturate, so a column whose lengths add up past 2^64 reports UINT64_MAX, not a small total.
 __global__ __launch_bounds__(1024) void scan_tile_sums_kernel(uint64_t *__restrict__ tile_sums,
                                                               uint64_t n_tiles) {
     __shared__ uint64_t wtot[16];
@@ -77,17 +97,19 @@ __global__ __launch_bounds__(1024) void scan_tile_sums_kernel(uint64_t *__restri
     for (uint64_t base = 0; base < n_tiles; base += 1024) {
         const uint64_t i = base + threadIdx.x;
         const uint64_t v = i < n_tiles ? tile_sums[i] : 0;
-        const uint64_t inc = wave_inclusive_sum(v, lane);
+        const uint64_t inc = wave_inclusive_sat_sum(v, lane);
+        uint64_t exc = __shfl_up((uint32_t)inc, 1) | ((uint64_t)__shfl_up((uint32_t)(inc >> 32), 1) << 32);
+        if (lane == 0) exc = 0;
         __syncthreads();
         if (lane == 63) wtot[wave] = inc;
         __syncthreads();
         uint64_t prefix = 0, total = 0;
         for (int w = 0; w < 16; w++) {
-            if (w < wave) prefix += wtot[w];
-            total += wtot[w];
+            if (w < wave) prefix = sat_add(prefix, wtot[w]);
+            total = sat_add(total, wtot[w]);
         }
-        if (i < n_tiles) tile_sums[i] = carry + prefix + inc - v;
-        carry += total;
+        if (i < n_tiles) tile_sums[i] = sat_add(sat_add(carry, prefix), exc);
+        carry = sat_add(carry, total);
     }
     if (threadIdx.x == 0) tile_sums[n_tiles] = carry;
 }
@@ -134,13 +156,14 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void scan_apply_kernel(
 }
 
 hipError_t launch_exclusive_scan_u64(hipStream_t st, uint64_t *data, uint64_t n,
-                                     uint64_t *block_sums) {
+                                     uint64_t *block_sums, uint64_t limit, uint32_t *over_flag) {
     const uint64_t n_tiles = (n + TILE_ITEMS - 1) / TILE_ITEMS;
     if (n_tiles == 0) {
         hipError_t e = hipMemsetAsync(data, 0, sizeof(uint64_t), st);
         return e;
     }
-    scan_reduce_kernel<<<(uint32_t)n_tiles, SCAN_WAVES * 64, 0, st>>>(data, n, block_sums);
+    scan_reduce_kernel<<<(uint32_t)n_tiles, SCAN_WAVES * 64, 0, st>>>(data, n, block_sums, limit,
+                                                                            over_flag);
     scan_tile_sums_kernel<<<1, 1024, 0, st>>>(block_sums, n_tiles);
     scan_apply_kernel<<<(uint32_t)n_tiles, SCAN_WAVES * 64, 0, st>>>(data, n, block_sums, n_tiles);
     return hipGetLastError();
@@ -189,11 +212,12 @@ __global__ __launch_bounds__(256) void utf8_bytes_kernel(const uint8_t *__restri
 
 __global__ __launch_bounds__(256) void utf8_offsets_kernel(const uint8_t *__restrict__ bytes,
                                                            const int64_t *__restrict__ offsets,
-                                                           uint64_t n, uint32_t *__restrict__ invalid) {
+                                                           uint64_t n, uint64_t total,
+                                                           uint32_t *__restrict__ invalid) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int64_t o = offsets[i], e = offsets[i + 1];
-    if (e > o && is_cont(bytes[o])) atomicOr(invalid, 1u);
+    const uint64_t o = (uint64_t)offsets[i], e = (uint64_t)offsets[i + 1];
+    if (e > o && o < total && is_cont(bytes[o])) atomicOr(invalid, 1u);
 }
 
 hipError_t launch_utf8_validate(hipStream_t st, const uint8_t *bytes, const int64_t *offsets,
@@ -203,7 +227,7 @@ hipError_t launch_utf8_validate(hipStream_t st, const uint8_t *bytes, const int6
                                                                                 invalid_flag);
     if (n)
         utf8_offsets_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(bytes, offsets, n,
-                                                                        invalid_flag);
+                                                                        total_bytes, invalid_flag);
     return hipGetLastError();
 }
 
@@ -212,15 +236,20 @@ hipError_t launch_utf8_validate(hipStream_t st, const uint8_t *bytes, const int6
 // ---------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void dictionary_lengths_kernel(
-    const int64_t *__restrict__ dict_offsets, uint64_t dict_size,
+    const int64_t *__restrict__ dict_offsets, uint64_t dict_size, uint64_t dict_total,
     const int64_t *__restrict__ indices, uint64_t n, uint64_t *__restrict__ lengths_out,
     uint32_t *__restrict__ error_flag) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t idx = (uint64_t)indices[i];
     uint64_t l = 0;
-    if (idx >= dict_size) atomicOr(error_flag, 1u);  // deserialize.rs:162 -> OutOfSpec
-    else l = (uint64_t)(dict_offsets[idx + 1] - dict_offsets[idx]);
+    if (idx >= dict_size) {
+        atomicOr(error_flag, 1u);  // deserialize.rs:162 -> OutOfSpec
+    } else {
+        const uint64_t b = (uint64_t)dict_offsets[idx], e = (uint64_t)dict_offsets[idx + 1];
+        if (e < b || e > dict_total) atomicOr(error_flag, 2u);  // not offsets of dict_bytes
+        else l = e - b;
+    }
     lengths_out[i] = l;
 }
 
@@ -241,11 +270,11 @@ __global__ __launch_bounds__(256) void dictionary_gather_kernel(
 }
 
 hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
-                                     const int64_t *indices, uint64_t n, uint64_t *lengths_out,
-                                     uint32_t *error_flag) {
+                                     uint64_t dict_total, const int64_t *indices, uint64_t n,
+                                     uint64_t *lengths_out, uint32_t *error_flag) {
     if (n == 0) return hipSuccess;
     dictionary_lengths_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(
-        dict_offsets, dict_size, indices, n, lengths_out, error_flag);
+        dict_offsets, dict_size, dict_total, indices, n, lengths_out, error_flag);
     return hipGetLastError();
 }
 

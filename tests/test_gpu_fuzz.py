@@ -1,0 +1,127 @@
+"""Malformed and mutated streams: the HIP decoder must agree with the oracle on success / failure
+and on every decoded value, and must never fault the GPU, whatever the bytes are."""
+import numpy as np
+import pytest
+
+import rle_encode as enc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from gpu_backend import GpuBackend
+    return GpuBackend()
+
+
+def _mutations(rng, stream, n_mut):
+    s = bytearray(stream)
+    out = []
+    for _ in range(n_mut):
+        m = bytearray(s)
+        kind = int(rng.integers(0, 4))
+        if kind == 0 and len(m):      # flip a few bytes
+            for _k in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+        elif kind == 1 and len(m):    # truncate
+            m = m[:int(rng.integers(0, len(m)))]
+        elif kind == 2:               # append garbage
+            m += bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8))
+        else:                         # corrupt a run header (the first bytes are one)
+            if len(m) > 2:
+                m[0] = int(rng.integers(0, 256))
+                m[1] = int(rng.integers(0, 256))
+        out.append(bytes(m))
+    return out
+
+
+@pytest.mark.parametrize("signed", [False, True])
+def test_rlev2_mutated_streams(gpu, oracle, signed):
+    rng = np.random.default_rng(100 + signed)
+    checked = errors = 0
+    for case in range(60):
+        n_runs = int(rng.integers(1, 12))
+        stream, expect, starts = enc.random_stream(rng, n_runs, signed, max_len=int(rng.choice([8, 64, 512])))
+        for m in _mutations(rng, stream, 6):
+            for n in {expect.size, max(1, expect.size // 2), expect.size + 7}:
+                rc_cpu, ref, _ = oracle.rlev2(m, n, signed)
+                rc_gpu, out, _ = gpu.rlev2(m, n, signed)
+                assert (rc_cpu == 0) == (rc_gpu == 0), (case, n, rc_cpu, rc_gpu, m.hex()[:200])
+                if rc_cpu == 0:
+                    assert (out == ref).all(), (case, n, m.hex()[:200])
+                    checked += 1
+                else:
+                    errors += 1
+    assert checked > 100 and errors > 100
+
+
+def test_rlev2_random_bytes(gpu, oracle):
+    rng = np.random.default_rng(7)
+    ok = 0
+    for case in range(300):
+        m = bytes(rng.integers(0, 256, size=int(rng.integers(1, 3000)), dtype=np.uint8))
+        n = int(rng.integers(1, 2000))
+        signed = bool(case & 1)
+        rc_cpu, ref, _ = oracle.rlev2(m, n, signed)
+        rc_gpu, out, _ = gpu.rlev2(m, n, signed)
+        assert (rc_cpu == 0) == (rc_gpu == 0), (case, n, rc_cpu, rc_gpu, m.hex()[:200])
+        if rc_cpu == 0:
+            assert (out == ref).all(), (case, m.hex()[:200])
+            ok += 1
+    assert ok > 10
+
+
+def test_patched_base_odd_patch_lists(gpu, oracle):
+    """Patch lists no writer emits: zero gaps after the first entry, gap fillers, positions past
+    the run -- the sequential readers' behaviour is the contract."""
+    rng = np.random.default_rng(9)
+    low = rng.integers(0, 256, size=40, dtype=np.uint64)
+    cases = [
+        [(3, 5), (0, 6), (4, 7)],            # zero gap: this entry and all later ones are dropped
+        [(0, 5), (0, 6)],
+        [(255, 0), (0, 9)],                  # filler then zero gap: position 255 (past the run)
+        [(10, 1), (255, 0), (0, 2)],
+        [(39, 3), (5, 4)],                   # second one past the end of the run
+        [(1, 1)] * 31,
+    ]
+    for patches in cases:
+        stream = enc.patched_base(1000, low, 8, patches, 12, 8)
+        rc_cpu, ref, _ = oracle.rlev2(stream, 40, True)
+        rc_gpu, out, _ = gpu.rlev2(stream, 40, True)
+        assert rc_cpu == 0 and rc_gpu == 0
+        assert (out == ref).all(), (patches, out.tolist(), ref.tolist())
+
+
+def test_byte_rle_mutated(gpu, oracle):
+    rng = np.random.default_rng(11)
+    for case in range(80):
+        data = bytearray(rng.integers(0, 4, size=int(rng.integers(1, 2000)), dtype=np.uint8))
+        stream = enc.byte_rle(data)
+        for m in _mutations(rng, stream, 5):
+            for n in {len(data), len(data) // 2 + 1, len(data) + 50}:
+                rc_cpu, ref = oracle.byte_rle(m, n)
+                rc_gpu, out = gpu.byte_rle(m, n)
+                assert (rc_cpu == 0) == (rc_gpu == 0), (case, n, rc_cpu, rc_gpu)
+                if rc_cpu == 0:
+                    assert (out == ref).all()
+                rc_cpu, ref, ones = oracle.boolean(m, n * 3)
+                rc_gpu, out, ones_gpu = gpu.boolean(m, n * 3)
+                assert (rc_cpu == 0) == (rc_gpu == 0)
+                if rc_cpu == 0:
+                    assert (out == ref).all() and ones == ones_gpu
+
+
+def test_string_lengths_versus_data(gpu, oracle):
+    rng = np.random.default_rng(13)
+    for case in range(40):
+        n = int(rng.integers(1, 3000))
+        lens = rng.integers(0, 20, size=n).astype(np.uint64)
+        ls = b"".join(enc.direct(lens[i:i + 512], 5, False) for i in range(0, n, 512))
+        total = int(lens.sum())
+        for data_len in (total, max(0, total - 1), total + 5, 0):
+            data = bytes(rng.integers(32, 127, size=data_len, dtype=np.uint8))
+            rc_cpu, off_ref, out_ref = oracle.string_direct(ls, data, n)
+            rc_gpu, off, out = gpu.string_direct(ls, data, n)
+            assert rc_cpu == rc_gpu, (case, data_len, rc_cpu, rc_gpu)
+            if rc_cpu == 0:
+                assert (off == off_ref).all() and out.tobytes() == out_ref.tobytes()
