@@ -30,7 +30,12 @@ WORKLOADS = {
                   "RLE v2 Delta, 10-bit deltas, runs of 512, monotonic int64, seed 43"),
     "delta_w16": ("delta_monotonic", {"width": 16}, True,
                   "RLE v2 Delta, 16-bit deltas, runs of 512, monotonic int64, seed 43"),
+    # direct-encoded string column: LENGTH (unsigned RLE v2 Direct, width 6) + DATA
+    "strings_w6": ("string_lengths_w6", {}, False,
+                   "string column, lengths U[8,56] as RLE v2 Direct width 6 runs of 512 (seed 46), "
+                   "ASCII DATA; offsets + copied bytes + UTF-8 validation"),
 }
+DEFAULT_ROWS = {"strings_w6": 250_000_000}
 
 
 def main():
@@ -38,7 +43,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=1_000_000_000, help="values per GPU per step")
+    ap.add_argument("--rows", type=int, default=None,
+                    help="values per GPU per step (default 1e9; 2.5e8 strings for strings_w6)")
     ap.add_argument("--workload", default="direct_w17", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--end-to-end", action="store_true",
@@ -68,10 +74,15 @@ def main():
     from orc_format_amd import Context
 
     gen_name, gen_kw, signed, desc = WORKLOADS[args.workload]
+    if args.rows is None:
+        args.rows = DEFAULT_ROWS.get(args.workload, 1_000_000_000)
+    if args.workload == "strings_w6":
+        return bench_strings(args, rank, world, local_rank, dist, desc, torch, np)
     n_runs = max(1, args.rows // 512)
     rows = n_runs * 512
     # every rank decodes a different stripe set (seed offset by rank)
     seed = {"direct_w17": 42, "delta_monotonic": 43}[gen_name] + 1000 * rank
+    full_size = rows == 1_000_000_000 - 1_000_000_000 % 512
     stream, entries, expect = getattr(synth, gen_name)(n_runs, seed=seed, device="cuda", **gen_kw)
     out = torch.empty(rows, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
@@ -146,22 +157,136 @@ def main():
     # HBM bytes per launch of the value kernel come from PMC counters, which cannot be read from
     # inside this process: they are taken from the newest committed rocprofv3 summary of this same
     # command and workload (separate FETCH_SIZE / WRITE_SIZE passes, see profiles/README.md).
-    if rows == 1_000_000_000 - 1_000_000_000 % 512:
-        import glob
-        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_%s_traffic.json" % args.workload)))
-        if found:
-            with open(found[-1]) as f:
-                prof = json.load(f)
-            k = prof.get("kernels", {}).get("orcd::rlev2_values_kernel")
-            if k:
-                result["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
-                result["roofline"]["traffic_source"] = os.path.relpath(found[-1], ROOT)
+    if full_size:
+        attach_traffic(result, args.workload, "rlev2_values_kernel")
 
     if args.end_to_end:
         result["end_to_end"] = end_to_end(args, ctx, stream, entries, expect, rows, signed, torch)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, stream, rows, stream_bytes, signed, expect, np)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def attach_traffic(result, workload, kernel):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_%s_traffic.json" % workload)))
+    if not found:
+        return
+    with open(found[-1]) as f:
+        prof = json.load(f)
+    for name, k in prof.get("kernels", {}).items():
+        if kernel in name and "hbm_bytes_per_launch" in k:
+            result["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = os.path.relpath(found[-1], ROOT)
+            return
+
+
+def bench_strings(args, rank, world, local_rank, dist, desc, torch, np):
+    """One step = one direct-encoded string column: LENGTH stream -> offsets[n + 1], DATA ->
+    copied bytes, every value checked to be UTF-8 (orcd_string_direct_decode)."""
+    from bench_util import synth
+    from orc_format_amd import Context, shard
+
+    n_runs = max(1, args.rows // 512)
+    n = n_runs * 512
+    lstream, entries, lengths = synth.string_lengths_w6(n_runs, seed=46 + 1000 * rank, device="cuda")
+    want_off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    want_off[0] = 0
+    torch.cumsum(lengths, 0, out=want_off[1:])
+    del lengths
+    total = int(want_off[-1].item())
+    data = torch.empty(total, dtype=torch.uint8, device="cuda")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4600 + rank)
+    for b0 in range(0, total, 1 << 28):   # printable ASCII, generated in pieces
+        b1 = min(total, b0 + (1 << 28))
+        data[b0:b1] = torch.randint(32, 127, (b1 - b0,), dtype=torch.uint8, device="cuda", generator=gen)
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    out = torch.empty(total, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx = Context(local_rank)
+
+    def step():
+        ctx.string_direct_device(lstream.data_ptr(), lstream.numel(), data.data_ptr(), total, n,
+                                 offsets.data_ptr(), out.data_ptr(), entries.data_ptr(),
+                                 entries.numel(), check_utf8=True)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    phase_ms = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for p in phase_ms:
+            phase_ms[p] += ctx.phase_ms(p)
+    barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist, device="cuda")
+    if not torch.equal(offsets, want_off):
+        raise SystemExit("bench.py: offsets differ from the prefix sums of the generated lengths")
+    if not torch.equal(out, data):
+        raise SystemExit("bench.py: copied string bytes differ from DATA")
+
+    decoded_bytes = total + 8 * (n + 1)
+    value = decoded_bytes * args.steps * world / elapsed / 1e9
+    k_ms = phase_ms[4] / args.steps
+    algo_bytes = 2 * total + 8 * (n + 1)   # bytes read + written once, offsets read once
+    achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    result = {
+        "metric": "device-resident decoded GB/s (RLEv2 int64 + strings) at 1/2/4/8 GPUs",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "strings_w6: %d strings per GPU per step; %s" % (n, desc),
+                   "strings_per_gpu": n, "data_bytes_per_gpu": total,
+                   "length_stream_bytes_per_gpu": int(lstream.numel()),
+                   "parallelism": "stripe-sharded x%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "string_bytes_kernel", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                     "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                     "avg_launch_ms": round(k_ms, 4)},
+        "phases_ms": {"header_count_scan_readback": round(phase_ms[1] / args.steps, 4),
+                      "run_table_emit": round(phase_ms[2] / args.steps, 4),
+                      "length_sums_scan_offsets": round(phase_ms[3] / args.steps, 4),
+                      "string_bytes_copy_validate": round(k_ms, 4)},
+        "decoded_frac_of_hbm_peak": round(value / world / HBM_PEAK_GBPS, 4),
+    }
+    if n == DEFAULT_ROWS["strings_w6"] - DEFAULT_ROWS["strings_w6"] % 512:
+        attach_traffic(result, args.workload, "string_bytes_kernel")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_ctypes
+        oracle = oracle_ctypes.load()
+
+        def run(n_vals):
+            n_vals = (n_vals // 512) * 512
+            ls = lstream[:n_vals // 512 * 386].cpu().numpy()
+            nbytes = int(want_off[n_vals].item())
+            host = data[:nbytes].cpu().numpy()
+            t0 = time.perf_counter()
+            rc, off, got = oracle.string_direct(ls, host, n_vals)
+            dt = time.perf_counter() - t0
+            assert rc == 0 and (off == want_off[:n_vals + 1].cpu().numpy()).all() and got.tobytes() == host.tobytes()
+            return n_vals, nbytes, dt
+        n_cal, _, dt_cal = run(min(n, 1 << 20))
+        n_s, nbytes, dt = run(int(min(n, max(n_cal, n_cal * args.cpu_seconds / max(dt_cal, 1e-6)))))
+        result["cpu_baseline"] = {
+            "value": round((nbytes + 8 * (n_s + 1)) / dt / 1e9, 4), "unit": "GB/s", "cores": 1,
+            "kind": "port", "sample": "first %d strings (%.1f MB of DATA) of the same column, single "
+                                      "thread, %.1f s" % (n_s, nbytes / 1e6, dt)}
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -82,7 +82,8 @@ int orcd_ctx_synchronize(orcd_ctx *ctx);
 float orcd_ctx_last_elapsed_ms(orcd_ctx *ctx);
 /* The same, per phase of the most recent decode call: 0 the whole call, 1 header count + segment
  * prefix sums (including the read-back the host waits for), 2 run-table emission, 3 value
- * expansion.  Negative when that phase did not run. */
+ * expansion (for strings: LENGTH sums, their scan and the expansion into offsets), 4 string
+ * bytes (copy + UTF-8 validation).  Negative when that phase did not run. */
 float orcd_ctx_phase_ms(orcd_ctx *ctx, int phase);
 /* Text of the last HIP runtime error seen by this context (after ORCD_HIP_ERROR). */
 const char *orcd_ctx_last_hip_error(orcd_ctx *ctx);

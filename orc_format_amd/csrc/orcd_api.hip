@@ -35,7 +35,7 @@ enum Slot {
     N_SLOTS
 };
 
-constexpr int N_EVENTS = 4;  // start, after header count + scan, after emit, after values
+constexpr int N_EVENTS = 5;  // start, after header count + scan, after emit, after values / offsets, after string bytes
 
 }  // namespace
 
@@ -506,6 +506,7 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
     if (!c || !offsets || (length_len && !length_stream) || (data_len && !data) ||
         (n_length_entries && !length_entry_points))
         return ORCD_INVALID_ARGUMENT;
+    if (data_len >= (1ull << 52)) return ORCD_INVALID_ARGUMENT;
     DeviceGuard g(c->device);
     reset_events(c);
     const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
@@ -516,29 +517,64 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
         ORCD_TRY(ensure(c, SLOT_OUT_A, (num_values + 1) * sizeof(int64_t), &p));
         d_offsets = (int64_t *)p;
     }
-    if (num_values) {
+    uint64_t total = 0;
+    if (num_values == 0) {
+        HIP_TRY(c, hipMemsetAsync(d_offsets, 0, sizeof(int64_t), c->stream));
+    } else {
         const void *d_len_stream, *d_entries;
         ORCD_TRY(stage_in(c, SLOT_IN_A, length_stream, length_len, in_dev, &d_len_stream));
         ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, length_entry_points, n_length_entries * sizeof(uint64_t),
                           in_dev, &d_entries));
-        // lengths land in offsets[0..n), then become offsets by an in-place exclusive prefix sum
-        ORCD_TRY(rlev2_device(c, (const uint8_t *)d_len_stream, length_len, num_values,
-                              (const uint64_t *)d_entries, n_length_entries, 0, d_offsets));
+        const uint8_t *ls = (const uint8_t *)d_len_stream;
+        Rlev2Table t;
+        ORCD_TRY(rlev2_table(c, ls, length_len, num_values, (const uint64_t *)d_entries,
+                             n_length_entries, 0, &t));
+        // Offsets are the exclusive prefix sums of the lengths (variable_length.rs:15-23: each
+        // next(len) continues where the last one ended).  The lengths themselves are never
+        // stored: one pass over the LENGTH stream reduces every group of runs to its sum, the
+        // few group sums are scanned, and a second pass expands the runs straight into offsets.
+        void *gsums, *sums, *flag;
+        ORCD_TRY(ensure(c, SLOT_TMP, ((size_t)t.n_groups + 1) * sizeof(uint64_t), &gsums));
+        ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(std::max<uint64_t>(num_values, t.n_groups)) * sizeof(uint64_t), &sums));
+        ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
+        HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
+        HIP_TRY(c, launch_rlev2_group_sums(c->stream, ls, length_len, t.runs, t.group_first, t.group_run,
+                                           t.n_groups, (uint32_t)t.total_runs, num_values, 0,
+                                           (uint64_t *)gsums, (uint32_t *)flag));
+        HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)gsums, t.n_groups, (uint64_t *)sums,
+                                             data_len, (uint32_t *)flag));
+        HIP_TRY(c, hipMemcpyAsync(c->h_scalars, (uint64_t *)gsums + t.n_groups, sizeof(uint64_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        uint32_t bad = *(uint32_t *)(c->h_scalars + 1);
+        total = c->h_scalars[0];
+        if (bad & 4u) {
+            // PatchedBase runs in the LENGTH stream: their patches are applied after the fact,
+            // so the lengths are materialised and scanned in place
+            HIP_TRY(c, launch_rlev2_values(c->stream, ls, length_len, t.runs, t.group_first, t.group_run,
+                                           t.n_groups, (uint32_t)t.total_runs, num_values, 0, d_offsets));
+            HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
+            HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)d_offsets, num_values,
+                                                 (uint64_t *)sums, data_len, (uint32_t *)flag));
+            HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_offsets + num_values, sizeof(uint64_t),
+                                      hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            bad = *(uint32_t *)(c->h_scalars + 1) & 1u;
+            total = c->h_scalars[0];
+            // Values::next would run out of bytes: one length alone, or their sum
+            if (bad || total > data_len) return ORCD_OUT_OF_SPEC;
+        } else {
+            if ((bad & 1u) || total > data_len) return ORCD_OUT_OF_SPEC;
+            HIP_TRY(c, launch_rlev2_offsets(c->stream, ls, length_len, t.runs, t.group_first, t.group_run,
+                                            t.n_groups, (uint32_t)t.total_runs, num_values, 0,
+                                            (const uint64_t *)gsums, d_offsets));
+            HIP_TRY(c, hipMemcpyAsync(d_offsets + num_values, (uint64_t *)gsums + t.n_groups,
+                                      sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+        }
     }
-    if (data_len >= (1ull << 52)) return ORCD_INVALID_ARGUMENT;
-    void *sums, *over;
-    ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(num_values) * sizeof(uint64_t), &sums));
-    ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &over));
-    HIP_TRY(c, hipMemsetAsync(over, 0, sizeof(uint32_t), c->stream));
-    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)d_offsets, num_values, (uint64_t *)sums,
-                                         data_len, (uint32_t *)over));
-    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_offsets + num_values, sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, over, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const uint64_t total = c->h_scalars[0];
-    // Values::next would run out of bytes (variable_length.rs:15-23): one length alone, or the sum
-    if (*(uint32_t *)(c->h_scalars + 1) || total > data_len) return ORCD_OUT_OF_SPEC;
+    mark(c, 3);
     const uint8_t *d_data = data;
     uint8_t *d_bytes = bytes_out;
     const bool want_utf8 = (flags & ORCD_CHECK_UTF8) && total;
@@ -548,29 +584,28 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
             ORCD_TRY(stage_in(c, SLOT_IN_B, data, total, false, &p));
             d_data = (const uint8_t *)p;
         }
-        if (bytes_out) {
-            if (!out_dev) {
-                d_bytes = const_cast<uint8_t *>(d_data);  // the staged copy is the result
-                if (in_dev) {
-                    void *p;
-                    ORCD_TRY(ensure(c, SLOT_OUT_B, total, &p));
-                    d_bytes = (uint8_t *)p;
-                }
+        if (bytes_out && !out_dev) {
+            d_bytes = const_cast<uint8_t *>(d_data);  // the staged copy is the result
+            if (in_dev) {
+                void *p;
+                ORCD_TRY(ensure(c, SLOT_OUT_B, total, &p));
+                d_bytes = (uint8_t *)p;
             }
-            if (d_bytes != d_data)
-                HIP_TRY(c, hipMemcpyAsync(d_bytes, d_data, total, hipMemcpyDeviceToDevice, c->stream));
         }
+        void *flag = nullptr;
         if (want_utf8) {
-            void *flag;
             ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
             HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
-            HIP_TRY(c, launch_utf8_validate(c->stream, d_data, d_offsets, num_values, (uint32_t *)flag, total));
+        }
+        HIP_TRY(c, launch_string_bytes(c->stream, d_data, bytes_out ? d_bytes : nullptr, d_offsets,
+                                       num_values, total, (uint32_t *)flag));
+        mark(c, 4);
+        if (want_utf8) {
             HIP_TRY(c, hipMemcpyAsync(c->h_scalars, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (*(uint32_t *)c->h_scalars) return ORCD_INVALID_UTF8;
         }
     }
-    mark(c, 3);
     if (!out_dev) {
         HIP_TRY(c, hipMemcpyAsync(offsets, d_offsets, (num_values + 1) * sizeof(int64_t),
                                   hipMemcpyDeviceToHost, c->stream));

@@ -107,6 +107,20 @@ hipError_t launch_rlev2_values(hipStream_t st, const uint8_t *stream, uint64_t l
                                const RunEntry *runs, const uint32_t *group_first,
                                const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
                                uint64_t num_values, int is_signed, int64_t *out);
+// The same expansion, reduced: group_sums[g] = saturating sum of the values of the runs that
+// start in the g-th window of 512 values (bit 2 of *flags is raised when a PatchedBase run was
+// met: its patches are not in the sums) ...
+hipError_t launch_rlev2_group_sums(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                   const RunEntry *runs, const uint32_t *group_first,
+                                   const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
+                                   uint64_t num_values, int is_signed, uint64_t *group_sums,
+                                   uint32_t *flags);
+// ... and, given the exclusive prefix sums of those, offsets[i] = sum of the values before i.
+hipError_t launch_rlev2_offsets(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                const RunEntry *runs, const uint32_t *group_first,
+                                const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
+                                uint64_t num_values, int is_signed, const uint64_t *group_prefix,
+                                int64_t *offsets);
 
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                                  const uint64_t *entries, uint32_t n_seg, const SegTable &t);
@@ -127,8 +141,12 @@ size_t scan_block_sums_len(uint64_t n);
 hipError_t launch_exclusive_scan_u64(hipStream_t st, uint64_t *data, uint64_t n,
                                      uint64_t *block_sums, uint64_t limit, uint32_t *over_flag);
 
-hipError_t launch_utf8_validate(hipStream_t st, const uint8_t *bytes, const int64_t *offsets,
-                                uint64_t n, uint32_t *invalid_flag, uint64_t total_bytes);
+// Copies total_bytes of string data to `dst` (when not null) and / or checks (when invalid_flag
+// is not null) that every value offsets[i]..offsets[i+1] is well-formed UTF-8; both in one pass
+// over the bytes.  offsets: n + 1 ascending values ending at total_bytes.
+hipError_t launch_string_bytes(hipStream_t st, const uint8_t *src, uint8_t *dst,
+                               const int64_t *offsets, uint64_t n, uint64_t total_bytes,
+                               uint32_t *invalid_flag);
 hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
                                      uint64_t dict_total, const int64_t *indices, uint64_t n,
                                      uint64_t *lengths_out, uint32_t *error_flag);

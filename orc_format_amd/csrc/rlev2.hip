@@ -385,6 +385,11 @@ constexpr int VAL_WAVES = 4;                   // wavefronts per workgroup
 constexpr uint32_t STAGE_BYTES = 4096 + 128;   // LDS slice per wavefront: any single run fits
 constexpr uint32_t STAGE_WORDS = STAGE_BYTES / 4 + 4;  // + padding for the 3-word extraction
 
+// What the expansion kernel does with the decoded values.
+constexpr int MODE_VALUES = 0;   // out[i] = value i
+constexpr int MODE_SUMS = 1;     // one saturating sum per group, nothing per value
+constexpr int MODE_OFFSETS = 2;  // out[i] = sum of the values before i (string offsets)
+
 struct Wave {
     const uint8_t *s;      // stream
     uint64_t len;          // its length: no load of the kernel may start at or after s + len
@@ -394,6 +399,14 @@ struct Wave {
     int lane;
     int is_signed;
     bool out_aligned;      // out is 16-byte aligned
+    // MODE_SUMS: this lane's share of the group's sum.  MODE_OFFSETS: sum of every value before
+    // the next one this wavefront emits (wave-uniform).
+    mutable uint64_t acc;
+    mutable uint32_t saw_patched;  // MODE_SUMS: a PatchedBase run was met (its patches are not summed)
+};
+template <int M>
+struct WaveOf : Wave {
+    static constexpr int MODE = M;
 };
 
 // Copies stream bytes [b0, b1) into the LDS slice; returns the stream offset that LDS byte 0
@@ -479,9 +492,39 @@ __device__ __forceinline__ void stream_store1(int64_t *dst, uint64_t v) {
     __builtin_nontemporal_store((int64_t)v, dst);
 }
 
+__device__ __forceinline__ uint64_t sat_add(uint64_t a, uint64_t b) {
+    const uint64_t t = a + b;
+    return t < a ? ~0ull : t;
+}
+
+__device__ __forceinline__ uint64_t wave_scan_dpp(uint64_t v);
+
+// Values -> what is stored in their place.  Every lane of the wavefront calls this for every
+// step, in ascending order of the values, with a0 / a1 false for values that are not this
+// wavefront's; MODE_OFFSETS relies on both.  Returns false when nothing is to be stored.
+template <class W>
+__device__ __forceinline__ bool transform_pair(const W &wv, uint64_t &v0, uint64_t &v1, bool a0,
+                                               bool a1) {
+    if (W::MODE == MODE_SUMS) {
+        wv.acc = sat_add(sat_add(wv.acc, a0 ? v0 : 0), a1 ? v1 : 0);
+        return false;
+    }
+    if (W::MODE == MODE_OFFSETS) {
+        // the totals were checked against the size of the data before this pass: no sum wraps
+        const uint64_t x = a0 ? v0 : 0, y = a1 ? v1 : 0;
+        const uint64_t incl = wave_scan_dpp(x + y);
+        v0 = wv.acc + incl - (x + y);
+        v1 = v0 + x;
+        wv.acc += readlane64(incl, 63);
+    }
+    return true;
+}
+
 // Two adjacent output values of one lane.
-__device__ __forceinline__ void store_pair(const Wave &wv, uint64_t e0, uint64_t v0, uint64_t v1,
+template <class W>
+__device__ __forceinline__ void store_pair(const W &wv, uint64_t e0, uint64_t v0, uint64_t v1,
                                            bool a0, bool a1) {
+    if (!transform_pair(wv, v0, v1, a0, a1)) return;
     int64_t *dst = wv.out + e0;
     if (a0 && a1 && wv.out_aligned) {
         stream_store2(dst, v0, v1);
@@ -511,8 +554,13 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v, int lane) {
 
 // PatchedBase: overwrites the patched positions of one run (all fields wave-uniform) after its
 // unpatched values have been written.  Lane j takes patch-list entry j.
-__device__ __forceinline__ void apply_patches(const Wave &wv, uint64_t desc, uint64_t base,
+template <class W>
+__device__ __forceinline__ void apply_patches(const W &wv, uint64_t desc, uint64_t base,
                                               uint64_t aux, uint64_t run_out) {
+    if (W::MODE != MODE_VALUES) {  // sums and offsets of patched runs go through MODE_VALUES
+        wv.saw_patched = 1;
+        return;
+    }
     const uint32_t w = desc_width(desc), rlen = desc_len(desc);
     const uint32_t pw = pb_patch_width(aux), pll = pb_list_len(aux), cfb = pb_entry_bits(aux);
     const uint8_t *p = wv.s + desc_payload(desc);
@@ -550,15 +598,17 @@ __device__ __forceinline__ void apply_patches(const Wave &wv, uint64_t desc, uin
 // masking and every store is a 16-byte one.  lo_rel / hi_rel bound the active values inside the
 // window otherwise.
 
-template <bool FULL>
-__device__ __forceinline__ void store_window_pair(const Wave &wv, int64_t *wout, uint32_t i_rel,
+template <bool FULL, class W>
+__device__ __forceinline__ void store_window_pair(const W &wv, int64_t *wout, uint32_t i_rel,
                                                   uint64_t v0, uint64_t v1, uint32_t lo_rel,
                                                   uint32_t hi_rel) {
     if (FULL) {
+        if (!transform_pair(wv, v0, v1, true, true)) return;
         stream_store2(wout + i_rel, v0, v1);
     } else {
         const bool a0 = i_rel >= lo_rel && i_rel < hi_rel;
         const bool a1 = i_rel + 1 >= lo_rel && i_rel + 1 < hi_rel;
+        if (!transform_pair(wv, v0, v1, a0, a1)) return;
         if (a0 && a1 && wv.out_aligned) {
             stream_store2(wout + i_rel, v0, v1);
         } else {
@@ -570,8 +620,8 @@ __device__ __forceinline__ void store_window_pair(const Wave &wv, int64_t *wout,
 
 // Direct and (unpatched) PatchedBase values of one window.  bit_lane: LDS bit position of the
 // packed field of this lane's first value of step 0.
-template <bool FULL, bool WIDE>
-__device__ __forceinline__ void direct_window(const Wave &wv, int64_t *wout, uint32_t w, bool zz,
+template <bool FULL, bool WIDE, class W>
+__device__ __forceinline__ void direct_window(const W &wv, int64_t *wout, uint32_t w, bool zz,
                                               uint64_t add, uint32_t bit_lane, uint32_t lo_rel,
                                               uint32_t hi_rel) {
 #pragma unroll
@@ -636,8 +686,8 @@ __device__ __forceinline__ uint64_t wave_scan_dpp(uint64_t v) {
 // deltas up to i.  Only the packed magnitudes are scanned; SUM is uint32_t when 510 of them cannot
 // overflow 32 bits (width <= 23).  idx0: index in the run of this lane's first value of step 0
 // (negative before the run).  carry: sum of the run's magnitudes before the current step.
-template <bool FULL, bool WIDE, typename SUM>
-__device__ __forceinline__ void delta_window(const Wave &wv, int64_t *wout, uint32_t w, bool neg,
+template <bool FULL, bool WIDE, typename SUM, class W>
+__device__ __forceinline__ void delta_window(const W &wv, int64_t *wout, uint32_t w, bool neg,
                                              uint64_t base, uint64_t delta_base, uint32_t bit_lane,
                                              int32_t idx0, uint32_t lo_rel, uint32_t hi_rel,
                                              uint64_t &carry) {
@@ -670,8 +720,8 @@ __device__ __forceinline__ void delta_window(const Wave &wv, int64_t *wout, uint
 }
 
 // ShortRepeat (step 0) and Delta without packed deltas: base + i * step.
-template <bool FULL>
-__device__ __forceinline__ void linear_window(const Wave &wv, int64_t *wout, uint64_t base,
+template <bool FULL, class W>
+__device__ __forceinline__ void linear_window(const W &wv, int64_t *wout, uint64_t base,
                                               uint64_t step, int32_t idx0, uint32_t lo_rel,
                                               uint32_t hi_rel) {
 #pragma unroll
@@ -683,7 +733,8 @@ __device__ __forceinline__ void linear_window(const Wave &wv, int64_t *wout, uin
     }
 }
 
-__device__ __forceinline__ void decode_single_run(const Wave &wv, uint64_t desc, uint64_t run_out,
+template <class W>
+__device__ __forceinline__ void decode_single_run(const W &wv, uint64_t desc, uint64_t run_out,
                                                   uint64_t base, uint64_t aux) {
     const uint32_t kind = desc_kind(desc), w = desc_width(desc), rlen = desc_len(desc);
     uint64_t run_end = run_out + rlen;
@@ -753,7 +804,8 @@ struct RunFields {
     uint32_t rel_out;  // out_off relative to the batch's first value
 };
 
-__device__ __forceinline__ void decode_run_batch(const Wave &wv, const RunEntry *runs, uint32_t rb,
+template <class W>
+__device__ __forceinline__ void decode_run_batch(const W &wv, const RunEntry *runs, uint32_t rb,
                                                  uint32_t nb) {
     const int lane = wv.lane;
     // lane k holds run rb + k of the batch
@@ -908,11 +960,16 @@ __device__ __forceinline__ void decode_run_batch(const Wave &wv, const RunEntry 
     }
 }
 
+// MODE_SUMS: group_sums[g] receives the (saturating) sum of the values of the runs that start in
+// window g; bit 2 of *flags is raised when a PatchedBase run was met, whose patches are not part of
+// the sums.  MODE_OFFSETS: group_sums[g] holds the sum of all values before group g, and out[i]
+// receives the sum of the values before i.
+template <int MODE>
 __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const RunEntry *__restrict__ runs,
     const uint32_t *__restrict__ group_first, const RunEntry *__restrict__ group_run,
     uint32_t n_groups, uint32_t n_runs, uint64_t num_values, int is_signed,
-    int64_t *__restrict__ out) {
+    int64_t *__restrict__ out, uint64_t *__restrict__ group_sums, uint32_t *__restrict__ flags) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[VAL_WAVES][STAGE_WORDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own: remap the
@@ -925,7 +982,7 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
     }
     const uint32_t g = wg * VAL_WAVES + wave;
     if (g >= n_groups) return;  // whole wavefront leaves; no workgroup barrier is used below
-    Wave wv;
+    WaveOf<MODE> wv;
     wv.s = s;
     wv.lds = stage[wave];
     wv.out = out;
@@ -934,26 +991,35 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
     wv.lane = threadIdx.x & 63;
     wv.is_signed = is_signed;
     wv.out_aligned = (((uintptr_t)out) & 15) == 0;
+    wv.acc = 0;
+    wv.saw_patched = 0;
+    if (MODE == MODE_OFFSETS) wv.acc = group_sums[g];  // wave-uniform address
 
     // The window's own copy of its first run: when that run is the only one starting in the
     // window (flagged by the header scan) nothing else has to be loaded.
-    {
-        const RunEntry *e = group_run + g;  // wave-uniform address
-        const uint64_t desc = readfirstlane64(e->desc);
-        if (desc & DESC_SINGLE) {
-            decode_single_run(wv, desc, readfirstlane64(e->out_off), readfirstlane64(e->base),
-                              readfirstlane64(e->aux));
-            return;
+    const RunEntry *e = group_run + g;  // wave-uniform address
+    const uint64_t desc = readfirstlane64(e->desc);
+    if (desc & DESC_SINGLE) {
+        decode_single_run(wv, desc, readfirstlane64(e->out_off), readfirstlane64(e->base),
+                          readfirstlane64(e->aux));
+    } else {
+        // the group's runs; clamped to the table so that a bad index can never walk off it
+        uint32_t r1 = __builtin_amdgcn_readfirstlane(group_first[g + 1]);
+        if (r1 > n_runs) r1 = n_runs;
+        uint32_t r0 = __builtin_amdgcn_readfirstlane(group_first[g]);
+        if (r0 > r1) r0 = r1;
+        for (uint32_t rb = r0; rb < r1; rb += 64) {
+            const uint32_t nb = (r1 - rb) < 64u ? (r1 - rb) : 64u;
+            decode_run_batch(wv, runs, rb, nb);
         }
     }
-    // the group's runs; clamped to the table so that a bad index can never walk off it
-    uint32_t r1 = __builtin_amdgcn_readfirstlane(group_first[g + 1]);
-    if (r1 > n_runs) r1 = n_runs;
-    uint32_t r0 = __builtin_amdgcn_readfirstlane(group_first[g]);
-    if (r0 > r1) r0 = r1;
-    for (uint32_t rb = r0; rb < r1; rb += 64) {
-        const uint32_t nb = (r1 - rb) < 64u ? (r1 - rb) : 64u;
-        decode_run_batch(wv, runs, rb, nb);
+    if (MODE == MODE_SUMS) {
+        uint64_t t = wv.acc;
+        for (int d = 32; d >= 1; d >>= 1) t = sat_add(t, shfl64(t, wv.lane ^ d));
+        if (wv.lane == 0) {
+            group_sums[g] = t;
+            if (wv.saw_patched) atomicOr(flags, 4u);
+        }
     }
 }
 
@@ -987,16 +1053,45 @@ hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len
     return hipGetLastError();
 }
 
+template <int MODE>
+static hipError_t launch_values_mode(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                     const RunEntry *runs, const uint32_t *group_first,
+                                     const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
+                                     uint64_t num_values, int is_signed, int64_t *out,
+                                     uint64_t *group_sums, uint32_t *flags) {
+    if (n_groups == 0) return hipSuccess;
+    const uint32_t blocks = (n_groups + VAL_WAVES - 1) / VAL_WAVES;
+    rlev2_values_kernel<MODE><<<blocks, VAL_WAVES * 64, 0, st>>>(
+        stream, len, runs, group_first, group_run, n_groups, n_runs, num_values, is_signed, out,
+        group_sums, flags);
+    return hipGetLastError();
+}
+
 hipError_t launch_rlev2_values(hipStream_t st, const uint8_t *stream, uint64_t len,
                                const RunEntry *runs, const uint32_t *group_first,
                                const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
                                uint64_t num_values, int is_signed, int64_t *out) {
-    if (n_groups == 0) return hipSuccess;
-    const uint32_t blocks = (n_groups + VAL_WAVES - 1) / VAL_WAVES;
-    rlev2_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, runs, group_first, group_run,
-                                                          n_groups, n_runs, num_values, is_signed,
-                                                          out);
-    return hipGetLastError();
+    return launch_values_mode<MODE_VALUES>(st, stream, len, runs, group_first, group_run, n_groups,
+                                           n_runs, num_values, is_signed, out, nullptr, nullptr);
+}
+
+hipError_t launch_rlev2_group_sums(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                   const RunEntry *runs, const uint32_t *group_first,
+                                   const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
+                                   uint64_t num_values, int is_signed, uint64_t *group_sums,
+                                   uint32_t *flags) {
+    return launch_values_mode<MODE_SUMS>(st, stream, len, runs, group_first, group_run, n_groups,
+                                         n_runs, num_values, is_signed, nullptr, group_sums, flags);
+}
+
+hipError_t launch_rlev2_offsets(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                const RunEntry *runs, const uint32_t *group_first,
+                                const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
+                                uint64_t num_values, int is_signed, const uint64_t *group_prefix,
+                                int64_t *offsets) {
+    return launch_values_mode<MODE_OFFSETS>(st, stream, len, runs, group_first, group_run, n_groups,
+                                            n_runs, num_values, is_signed, offsets,
+                                            const_cast<uint64_t *>(group_prefix), nullptr);
 }
 
 }  // namespace orcd

@@ -170,64 +170,179 @@ hipError_t launch_exclusive_scan_u64(hipStream_t st, uint64_t *data, uint64_t n,
 }
 
 // ---------------------------------------------------------------------------------------------
-// UTF-8 validation (std::str::from_utf8 acceptance, tests/it/deserialize.rs:116-118)
+// String bytes: copy and UTF-8 validation in one pass
+// (std::str::from_utf8 acceptance, tests/it/deserialize.rs:116-118)
 //
 // Every value is well formed iff the concatenated bytes are well formed and no value starts on a
-// continuation byte, so bytes are checked position-parallel and offsets separately.
+// continuation byte.  Well-formedness of the concatenation is decided position by position from a
+// byte and its three predecessors:
+//   * a byte is a continuation byte (10xxxxxx) exactly when one is owed -- the previous byte is a
+//     lead (>= C0), or the one before is a 3/4-byte lead (>= E0), or the one before that a 4-byte
+//     lead (>= F0);
+//   * C0, C1 and F5..FF never occur;
+//   * after E0 the next byte is >= A0, after ED < A0, after F0 >= 90, after F4 < 90.
+// One more position just past the last byte, holding a non-continuation byte, catches a sequence
+// cut short by the end of the data.
+//
+// A workgroup takes a tile of 64 KiB of 16-byte chunks (aligned to the source address), each lane
+// a chunk at a time as four little-endian dwords examined with byte-parallel arithmetic; then the
+// workgroup looks up which values start inside its tile (two 64-ary searches of the offsets) and
+// tests their first bytes, which it has just pulled into the cache.
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ bool is_cont(uint32_t b) { return (b & 0xC0) == 0x80; }
+constexpr uint32_t SB_THREADS = 256;
+constexpr uint32_t SB_CHUNKS_PER_THREAD = 16;
+constexpr uint32_t SB_TILE_CHUNKS = SB_THREADS * SB_CHUNKS_PER_THREAD;  // 64 KiB
+constexpr uint32_t HI = 0x80808080u;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void utf8_bytes_kernel(const uint8_t *__restrict__ bytes,
-                                                         uint64_t n, uint32_t *__restrict__ invalid) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t c = bytes[i];
-    bool ok = true;
-    if (c < 0x80) {
-        ok = true;
-    } else if (is_cont(c)) {
-        // must be claimed by a lead byte at most 3 positions back
-        const uint32_t p1 = i >= 1 ? bytes[i - 1] : 0, p2 = i >= 2 ? bytes[i - 2] : 0,
-                       p3 = i >= 3 ? bytes[i - 3] : 0;
-        ok = (p1 >= 0xC2 && p1 <= 0xF4) || (is_cont(p1) && p2 >= 0xE0 && p2 <= 0xF4) ||
-             (is_cont(p1) && is_cont(p2) && p3 >= 0xF0 && p3 <= 0xF4);
-    } else {
-        const uint32_t need = c >= 0xF0 ? 3 : (c >= 0xE0 ? 2 : 1);
-        if (c < 0xC2 || c > 0xF4 || i + need > n - 1) {
-            ok = false;
+// per byte: x >= c, for c >= 0x80; result in bit 7 of each byte
+__device__ __forceinline__ uint32_t bytes_ge(uint32_t x, uint32_t c) {
+    return x & ((x | HI) - ((c & 0x7Fu) * 0x01010101u)) & HI;
+}
+
+// Errors (bit 7 of the offending bytes) among the 4 bytes of `d`, whose predecessors are the
+// top bytes of `before` (the dword in front of it).
+__device__ __forceinline__ uint32_t utf8_errors(uint32_t d, uint32_t before) {
+    const uint32_t p1 = __builtin_amdgcn_alignbyte(d, before, 3);
+    const uint32_t p2 = __builtin_amdgcn_alignbyte(d, before, 2);
+    const uint32_t p3 = __builtin_amdgcn_alignbyte(d, before, 1);
+    const uint32_t cont = d & ~(d << 1) & HI;
+    const uint32_t owed = (p1 & (p1 << 1)) | (p2 & (p2 << 1) & (p2 << 2)) |
+                          (p3 & (p3 << 1) & (p3 << 2) & (p3 << 3));
+    uint32_t err = (owed ^ cont) & HI;
+    err |= (d & (d << 1) & HI) & ~bytes_ge(d, 0xC2);  // C0, C1
+    if ((d | p1) & ((d | p1) << 1) & ((d | p1) << 2) & HI) {  // some byte or predecessor >= E0
+        err |= bytes_ge(d, 0xF5);
+        const uint32_t b5 = d << 2, b54 = (d << 2) | (d << 3);  // bit 5, bit 5 or 4 -> bit 7
+        const uint32_t e0 = bytes_ge(p1, 0xE0) & ~bytes_ge(p1, 0xE1);
+        const uint32_t ed = bytes_ge(p1, 0xED) & ~bytes_ge(p1, 0xEE);
+        const uint32_t f0 = bytes_ge(p1, 0xF0) & ~bytes_ge(p1, 0xF1);
+        const uint32_t f4 = bytes_ge(p1, 0xF4) & ~bytes_ge(p1, 0xF5);
+        err |= (e0 & ~b5) | (ed & b5) | (f0 & ~b54) | (f4 & b54);
+    }
+    return err;
+}
+
+// dword whose bytes k (data index idx0 + k) outside [0, total) are cleared
+__device__ __forceinline__ uint32_t clip_dword(uint32_t d, int64_t idx0, uint64_t total) {
+    uint32_t m = 0;
+    for (int k = 0; k < 4; k++)
+        if (idx0 + k >= 0 && (uint64_t)(idx0 + k) < total) m |= 0xFFu << (8 * k);
+    return d & m;
+}
+
+// first i in [0, n_off) with offsets[i] >= key (n_off if none); all 64 lanes take part
+__device__ __forceinline__ uint64_t wave_lower_bound(const int64_t *__restrict__ offsets,
+                                                     uint64_t n_off, uint64_t key, int lane) {
+    uint64_t a = 0, b = n_off;  // offsets[i] < key for i < a; offsets[i] >= key for i >= b
+    while (a < b) {
+        const uint64_t step = (b - a + 63) / 64;
+        const uint64_t p = a + (uint64_t)lane * step;
+        const bool below = p < b && (uint64_t)offsets[p] < key;
+        const uint32_t k = (uint32_t)__popcll(__ballot(below));  // the lanes below form a prefix
+        if (k == 0) {
+            b = a;
         } else {
-            const uint32_t c1 = bytes[i + 1];
-            ok = is_cont(c1);
-            if (c == 0xE0) ok = ok && c1 >= 0xA0;
-            if (c == 0xED) ok = ok && c1 <= 0x9F;
-            if (c == 0xF0) ok = ok && c1 >= 0x90;
-            if (c == 0xF4) ok = ok && c1 <= 0x8F;
-            if (need >= 2) ok = ok && is_cont(bytes[i + 2]);
-            if (need >= 3) ok = ok && is_cont(bytes[i + 3]);
+            const uint64_t last_below = a + (uint64_t)(k - 1) * step;
+            const uint64_t next_probe = last_below + step;
+            b = (k < 64 && next_probe < b) ? next_probe : b;
+            a = last_below + 1;
+            if (b < a) b = a;
         }
     }
-    if (!ok) atomicOr(invalid, 1u);
+    return a;
 }
 
-__global__ __launch_bounds__(256) void utf8_offsets_kernel(const uint8_t *__restrict__ bytes,
-                                                           const int64_t *__restrict__ offsets,
-                                                           uint64_t n, uint64_t total,
-                                                           uint32_t *__restrict__ invalid) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t o = (uint64_t)offsets[i], e = (uint64_t)offsets[i + 1];
-    if (e > o && o < total && is_cont(bytes[o])) atomicOr(invalid, 1u);
+template <bool COPY, bool CHECK>
+__global__ __launch_bounds__(SB_THREADS) void string_bytes_kernel(
+    const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int64_t *__restrict__ offsets,
+    uint64_t n, uint64_t total, uint32_t *__restrict__ invalid) {
+    __shared__ uint64_t bounds[2];
+    const uint32_t skew = (uint32_t)((uintptr_t)src & 15);
+    const uint4 *chunks = (const uint4 *)(src - skew);  // chunk c holds data bytes 16c - skew ...
+    uint4 *out_chunks = COPY ? (uint4 *)(dst - skew) : nullptr;  // dst has the same skew
+    const uint64_t c_begin = (uint64_t)blockIdx.x * SB_TILE_CHUNKS;
+    uint32_t err = 0;
+#pragma unroll 4
+    for (uint32_t k = 0; k < SB_CHUNKS_PER_THREAD; k++) {
+        const uint64_t c = c_begin + (uint64_t)k * SB_THREADS + threadIdx.x;
+        const int64_t idx0 = (int64_t)(c * 16) - (int64_t)skew;  // data index of the chunk's byte 0
+        if (idx0 > (int64_t)total) continue;  // the chunk that holds index `total` is the last one
+        const bool inside = idx0 >= 0 && (uint64_t)idx0 + 16 <= total;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (inside || (idx0 + 16 > 0 && (uint64_t)(idx0 < 0 ? 0 : idx0) < total)) v = chunks[c];
+        if (COPY) {
+            if (inside) {
+                u32x4 t;
+                t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+                __builtin_nontemporal_store(t, (u32x4 *)(out_chunks + c));
+            } else {
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+                for (int j = 0; j < 16; j++)
+                    if (idx0 + j >= 0 && (uint64_t)(idx0 + j) < total)
+                        dst[idx0 + j] = (uint8_t)(d[j >> 2] >> (8 * (j & 3)));
+            }
+        }
+        if (CHECK) {
+            // the dword in front of the chunk supplies the three predecessors of its first byte
+            uint32_t before = 0;
+            if (idx0 >= 4) before = ((const uint32_t *)chunks)[c * 4 - 1];
+            else if (idx0 > 0) before = clip_dword(((const uint32_t *)chunks)[c * 4 - 1], idx0 - 4, total);
+            if (!inside) {
+                v.x = clip_dword(v.x, idx0, total);
+                v.y = clip_dword(v.y, idx0 + 4, total);
+                v.z = clip_dword(v.z, idx0 + 8, total);
+                v.w = clip_dword(v.w, idx0 + 12, total);
+            }
+            if (((v.x | v.y | v.z | v.w) | (before & 0xFFFFFF00u)) & HI) {  // not plain ASCII
+                err |= utf8_errors(v.x, before) | utf8_errors(v.y, v.x) | utf8_errors(v.z, v.y) |
+                       utf8_errors(v.w, v.z);
+            }
+        }
+    }
+    if (!CHECK) return;
+    // values that start inside this tile must not start on a continuation byte
+    const int64_t t0s = (int64_t)(c_begin * 16) - (int64_t)skew;
+    const uint64_t t0 = t0s < 0 ? 0 : (uint64_t)t0s;
+    uint64_t t1 = (uint64_t)(t0s + (int64_t)SB_TILE_CHUNKS * 16);
+    if (t1 > total) t1 = total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave < 2) {
+        const uint64_t r = wave_lower_bound(offsets, n + 1, wave == 0 ? t0 : t1, lane);
+        if (lane == 0) bounds[wave] = r;
+    }
+    __syncthreads();
+    const uint64_t lo = bounds[0], hi = bounds[1] < n ? bounds[1] : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += SB_THREADS) {
+        const uint64_t o = (uint64_t)offsets[i], e = (uint64_t)offsets[i + 1];
+        if (e > o && o < total && (src[o] & 0xC0) == 0x80) err |= HI;
+    }
+    if (err) atomicOr(invalid, 1u);
 }
 
-hipError_t launch_utf8_validate(hipStream_t st, const uint8_t *bytes, const int64_t *offsets,
-                                uint64_t n, uint32_t *invalid_flag, uint64_t total_bytes) {
-    if (total_bytes)
-        utf8_bytes_kernel<<<(uint32_t)((total_bytes + 255) / 256), 256, 0, st>>>(bytes, total_bytes,
-                                                                                invalid_flag);
-    if (n)
-        utf8_offsets_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(bytes, offsets, n,
-                                                                        total_bytes, invalid_flag);
+hipError_t launch_string_bytes(hipStream_t st, const uint8_t *src, uint8_t *dst,
+                               const int64_t *offsets, uint64_t n, uint64_t total,
+                               uint32_t *invalid_flag) {
+    if (total == 0 || (!dst && !invalid_flag)) return hipSuccess;
+    if (dst == src) dst = nullptr;
+    // the copy shares the source's 16-byte chunking: other placements go through the runtime's copy
+    if (dst && (((uintptr_t)dst ^ (uintptr_t)src) & 15)) {
+        hipError_t e = hipMemcpyAsync(dst, src, total, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+        dst = nullptr;
+        if (!invalid_flag) return hipSuccess;
+    }
+    const uint64_t skew = (uintptr_t)src & 15;
+    const uint64_t n_chunks = (total + skew) / 16 + 1;  // up to the chunk that holds index `total`
+    const uint64_t tiles = (n_chunks + SB_TILE_CHUNKS - 1) / SB_TILE_CHUNKS;
+    if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (dst && invalid_flag)
+        string_bytes_kernel<true, true><<<(uint32_t)tiles, SB_THREADS, 0, st>>>(src, dst, offsets, n, total, invalid_flag);
+    else if (dst)
+        string_bytes_kernel<true, false><<<(uint32_t)tiles, SB_THREADS, 0, st>>>(src, dst, offsets, n, total, invalid_flag);
+    else
+        string_bytes_kernel<false, true><<<(uint32_t)tiles, SB_THREADS, 0, st>>>(src, dst, offsets, n, total, invalid_flag);
     return hipGetLastError();
 }
 
