@@ -262,22 +262,31 @@ __global__ __launch_bounds__(SB_THREADS) void string_bytes_kernel(
     const uint32_t skew = (uint32_t)((uintptr_t)src & 15);
     const uint4 *chunks = (const uint4 *)(src - skew);  // chunk c holds data bytes 16c - skew ...
     uint4 *out_chunks = COPY ? (uint4 *)(dst - skew) : nullptr;  // dst has the same skew
-    const uint64_t c_begin = (uint64_t)blockIdx.x * SB_TILE_CHUNKS;
-    uint32_t err = 0;
-#pragma unroll 4
+    // workgroups that share an XCD (equal id modulo 8) walk one contiguous eighth of the tiles
+    uint32_t tile = blockIdx.x;
+    {
+        const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = tile % 8;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + tile / 8;
+    }
+    const uint64_t c_begin = (uint64_t)tile * SB_TILE_CHUNKS;
+    uint32_t err = 0, high = 0;
+#pragma unroll 8
     for (uint32_t k = 0; k < SB_CHUNKS_PER_THREAD; k++) {
         const uint64_t c = c_begin + (uint64_t)k * SB_THREADS + threadIdx.x;
         const int64_t idx0 = (int64_t)(c * 16) - (int64_t)skew;  // data index of the chunk's byte 0
-        if (idx0 > (int64_t)total) continue;  // the chunk that holds index `total` is the last one
+        // the chunk that holds index `total` is the last one with anything to do
+        const bool live = idx0 <= (int64_t)total;
         const bool inside = idx0 >= 0 && (uint64_t)idx0 + 16 <= total;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (inside || (idx0 + 16 > 0 && (uint64_t)(idx0 < 0 ? 0 : idx0) < total)) v = chunks[c];
+        if (inside || (live && idx0 + 16 > 0 && (uint64_t)(idx0 < 0 ? 0 : idx0) < total)) {
+            v = chunks[c];  // (a nontemporal load measured no faster)
+        }
         if (COPY) {
             if (inside) {
                 u32x4 t;
                 t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
                 __builtin_nontemporal_store(t, (u32x4 *)(out_chunks + c));
-            } else {
+            } else if (live) {
                 const uint32_t d[4] = {v.x, v.y, v.z, v.w};
                 for (int j = 0; j < 16; j++)
                     if (idx0 + j >= 0 && (uint64_t)(idx0 + j) < total)
@@ -285,16 +294,21 @@ __global__ __launch_bounds__(SB_THREADS) void string_bytes_kernel(
             }
         }
         if (CHECK) {
-            // the dword in front of the chunk supplies the three predecessors of its first byte
-            uint32_t before = 0;
-            if (idx0 >= 4) before = ((const uint32_t *)chunks)[c * 4 - 1];
-            else if (idx0 > 0) before = clip_dword(((const uint32_t *)chunks)[c * 4 - 1], idx0 - 4, total);
-            if (!inside) {
+            if (!inside) {  // bytes that are not data read as zero
                 v.x = clip_dword(v.x, idx0, total);
                 v.y = clip_dword(v.y, idx0 + 4, total);
                 v.z = clip_dword(v.z, idx0 + 8, total);
                 v.w = clip_dword(v.w, idx0 + 12, total);
             }
+            // The dword in front of the chunk supplies the three predecessors of its first byte:
+            // the neighbouring lane holds it, except for the first lane of the wavefront.
+            uint32_t before = __shfl_up(v.w, 1);
+            if ((threadIdx.x & 63) == 0) {
+                before = 0;
+                if (live && idx0 > 0)
+                    before = clip_dword(((const uint32_t *)chunks)[c * 4 - 1], idx0 - 4, total);
+            }
+            high |= v.x | v.y | v.z | v.w;
             if (((v.x | v.y | v.z | v.w) | (before & 0xFFFFFF00u)) & HI) {  // not plain ASCII
                 err |= utf8_errors(v.x, before) | utf8_errors(v.y, v.x) | utf8_errors(v.z, v.y) |
                        utf8_errors(v.w, v.z);
@@ -302,7 +316,12 @@ __global__ __launch_bounds__(SB_THREADS) void string_bytes_kernel(
         }
     }
     if (!CHECK) return;
-    // values that start inside this tile must not start on a continuation byte
+    // Values that start inside this tile must not start on a continuation byte; a tile of plain
+    // ASCII has none.
+    if (!__syncthreads_or((high & HI) != 0)) {
+        if (err) atomicOr(invalid, 1u);
+        return;
+    }
     const int64_t t0s = (int64_t)(c_begin * 16) - (int64_t)skew;
     const uint64_t t0 = t0s < 0 ? 0 : (uint64_t)t0s;
     uint64_t t1 = (uint64_t)(t0s + (int64_t)SB_TILE_CHUNKS * 16);
