@@ -34,8 +34,12 @@ WORKLOADS = {
     "strings_w6": ("string_lengths_w6", {}, False,
                    "string column, lengths U[8,56] as RLE v2 Direct width 6 runs of 512 (seed 46), "
                    "ASCII DATA; offsets + copied bytes + UTF-8 validation"),
+    # PRESENT / boolean DATA: byte-RLE (literal groups and runs) -> one byte per value + count
+    "boolean_mix": ("byte_rle_mix", {}, False,
+                    "boolean stream, byte-RLE mix of 128-byte literal groups (70%) and 130-byte runs "
+                    "of 0xff (30%), seed 45; one byte per value + number of set bits"),
 }
-DEFAULT_ROWS = {"strings_w6": 250_000_000}
+DEFAULT_ROWS = {"strings_w6": 250_000_000, "boolean_mix": 4_000_000_000}
 
 
 def main():
@@ -78,6 +82,8 @@ def main():
         args.rows = DEFAULT_ROWS.get(args.workload, 1_000_000_000)
     if args.workload == "strings_w6":
         return bench_strings(args, rank, world, local_rank, dist, desc, torch, np)
+    if args.workload == "boolean_mix":
+        return bench_boolean(args, rank, world, local_rank, dist, desc, torch, np)
     n_runs = max(1, args.rows // 512)
     rows = n_runs * 512
     # every rank decodes a different stripe set (seed offset by rank)
@@ -306,6 +312,100 @@ def bench_strings(args, rank, world, local_rank, dist, desc, torch, np):
             "value": round((nbytes + 8 * (n_s + 1)) / dt / 1e9, 4), "unit": "GB/s", "cores": 1,
             "kind": "port", "sample": "first %d strings (%.1f MB of DATA) of the same column, single "
                                       "thread, %.1f s" % (n_s, nbytes / 1e6, dt)}
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_boolean(args, rank, world, local_rank, dist, desc, torch, np):
+    """One step = one boolean stream (PRESENT or boolean DATA): byte-RLE -> Vec<bool>-style bytes
+    and the number of set bits (orcd_boolean_decode)."""
+    from bench_util import synth
+    from orc_format_amd import Context, shard
+
+    n_blocks = max(1, args.rows // 8 // 129)
+    stream, entries, packed = synth.byte_rle_mix(n_blocks, seed=45 + 1000 * rank, device="cuda")
+    num_bits = packed.numel() * 8 - 3          # not a multiple of 8: the last byte is partial
+    want = synth.unpack_bools(packed, num_bits)
+    want_ones = int(want.sum(dtype=torch.int64).item())
+    out = torch.empty(num_bits, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx = Context(local_rank)
+    ones = [0]
+
+    def step():
+        ones[0] = ctx.boolean_device(stream.data_ptr(), stream.numel(), num_bits, out.data_ptr(), 0,
+                                     entries.data_ptr(), entries.numel(), want_count=True)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    phase_ms = {1: 0.0, 2: 0.0, 3: 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for p in phase_ms:
+            phase_ms[p] += ctx.phase_ms(p)
+    barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist, device="cuda")
+    if ones[0] != want_ones or not torch.equal(out, want):
+        raise SystemExit("bench.py: decoded booleans differ from the generator's")
+
+    decoded_bytes = num_bits
+    value = decoded_bytes * args.steps * world / elapsed / 1e9
+    k_ms = phase_ms[3] / args.steps
+    algo_bytes = num_bits + int(stream.numel())
+    achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    result = {
+        "metric": "device-resident decoded GB/s (RLEv2 int64 + strings) at 1/2/4/8 GPUs",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "boolean_mix: %d values per GPU per step; %s" % (num_bits, desc),
+                   "values_per_gpu": num_bits, "stream_bytes_per_gpu": int(stream.numel()),
+                   "entry_points_per_gpu": int(entries.numel()),
+                   "parallelism": "stripe-sharded x%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "bool_expand_kernel", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                     "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                     "avg_launch_ms": round(k_ms, 4)},
+        "phases_ms": {"header_count_scan_readback": round(phase_ms[1] / args.steps, 4),
+                      "run_table_emit": round(phase_ms[2] / args.steps, 4),
+                      "expand_to_booleans": round(k_ms, 4)},
+        "decoded_frac_of_hbm_peak": round(value / world / HBM_PEAK_GBPS, 4),
+    }
+    if args.rows == DEFAULT_ROWS["boolean_mix"]:
+        attach_traffic(result, args.workload, "bool_expand_kernel")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_ctypes
+        oracle = oracle_ctypes.load()
+
+        def run(n_entries):
+            nbytes = int(entries[n_entries].item()) if n_entries < entries.numel() else int(stream.numel())
+            host = stream[:nbytes].cpu().numpy()
+            # decoded bytes of the first n_entries * 10 blocks
+            n_bits = min(num_bits, 8 * 128 * 10 * n_entries)   # a lower bound of what the prefix holds
+            t0 = time.perf_counter()
+            rc, vals, cnt = oracle.boolean(host, n_bits)
+            dt = time.perf_counter() - t0
+            assert rc == 0 and (vals == want[:n_bits].cpu().numpy().astype(bool)).all()
+            return n_bits, dt
+        n_cal, dt_cal = run(min(entries.numel(), 2000))
+        scale = args.cpu_seconds / max(dt_cal, 1e-6)
+        n_s, dt = run(int(min(entries.numel(), max(2000, 2000 * scale))))
+        result["cpu_baseline"] = {
+            "value": round(n_s / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "first %d values of the same stream, single thread, %.1f s" % (n_s, dt)}
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -129,3 +129,44 @@ def string_lengths_w6(n_runs, seed=46, runs_per_entry=20, device="cuda", chunk_r
         stream[r0:r1, 2:] = pack_bits(ln, 6)
     entries = torch.arange(0, n_runs, runs_per_entry, dtype=torch.int64, device=device) * run_bytes
     return stream.view(-1), entries, lengths.view(-1)
+
+
+def byte_rle_mix(n_blocks, seed=45, run_fraction=0.3, blocks_per_entry=10, device="cuda"):
+    """Byte-RLE stream (PRESENT / boolean DATA shape): a random mix of literal groups (control
+    0x80 + 128 random bytes) and runs (control 0x7f: 130 copies of 0xff, "all valid").
+    Returns (stream uint8, entries int64 = offsets of every `blocks_per_entry`-th control byte,
+    decoded bytes uint8)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    is_run = torch.rand(n_blocks, device=device, generator=g) < run_fraction
+    size_in = torch.where(is_run, 2, 129)
+    size_out = torch.where(is_run, 130, 128)
+    in_off = torch.cumsum(size_in, 0) - size_in
+    out_off = torch.cumsum(size_out, 0) - size_out
+    total_in = int(size_in.sum())
+    total_out = int(size_out.sum())
+    stream = torch.zeros(total_in, dtype=torch.uint8, device=device)
+    decoded = torch.full((total_out,), 0xFF, dtype=torch.uint8, device=device)
+    stream[in_off] = torch.where(is_run, 0x7F, 0x80).to(torch.uint8)
+    stream[in_off[is_run] + 1] = 0xFF
+    lit_in = in_off[~is_run] + 1
+    lit_out = out_off[~is_run]
+    j = torch.arange(128, device=device)
+    for b0 in range(0, lit_in.numel(), 1 << 20):   # in pieces: the index tensors are 8x the data
+        b1 = min(lit_in.numel(), b0 + (1 << 20))
+        payload = torch.randint(0, 256, (b1 - b0, 128), dtype=torch.uint8, device=device, generator=g)
+        stream[(lit_in[b0:b1, None] + j).view(-1)] = payload.view(-1)
+        decoded[(lit_out[b0:b1, None] + j).view(-1)] = payload.view(-1)
+    entries = in_off[::blocks_per_entry].contiguous()
+    return stream, entries, decoded
+
+
+def unpack_bools(packed, num_bits):
+    """MSB-first bits of `packed` as one uint8 (0/1) per value."""
+    sh = torch.arange(7, -1, -1, device=packed.device, dtype=torch.uint8)
+    out = torch.empty(packed.numel() * 8, dtype=torch.uint8, device=packed.device)
+    step = 1 << 26
+    for b0 in range(0, packed.numel(), step):
+        b1 = min(packed.numel(), b0 + step)
+        out[b0 * 8:b1 * 8] = ((packed[b0:b1, None] >> sh) & 1).view(-1)
+    return out[:num_bits]

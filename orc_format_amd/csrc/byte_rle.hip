@@ -5,17 +5,30 @@
 // stream carries 8 values per byte, most significant bit first (boolean_rle.rs:98,118).  Run and
 // literal lengths are exactly those of the ORC specification.  Same two-phase shape as the RLE v2
 // decoder: control bytes form a serial chain walked per segment, then the bytes are expanded.
+#include <algorithm>
+
 #include "orcd_internal.h"
 #include "seg_scan.h"
 
 namespace orcd {
 
 constexpr uint64_t BR_IS_RUN = 1ull << 48;
+constexpr uint32_t BR_WINDOW_SHIFT = 7;  // the expansion looks runs up per window of 128 bytes
+constexpr uint32_t BR_WINDOW = 1u << BR_WINDOW_SHIFT;
 
+size_t byte_rle_window_slots(uint64_t total_bytes) {
+    return (size_t)((total_bytes + BR_WINDOW - 1) >> BR_WINDOW_SHIFT) + 1;
+}
+
+// COUNT pass: runs and bytes per segment.  EMIT pass: the run table, a sentinel run one past the
+// end, and win_first[w] = index of the first run that starts inside or after window w.  A run is
+// at most 130 bytes, so it can span at most one whole window in which nothing starts; the lane
+// that emits the run fills that slot, and the last lane fills the slots past the last run start.
 template <bool EMIT>
 __global__ __launch_bounds__(SEG_BLOCK) void byte_rle_scan_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
-    uint32_t n_seg, SegTable t, ByteRun *__restrict__ runs) {
+    uint32_t n_seg, SegTable t, ByteRun *__restrict__ runs, uint32_t *__restrict__ win_first,
+    uint32_t n_win_slots) {
     const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
     const bool valid = seg < n_seg;
     if (EMIT && !valid) return;
@@ -26,11 +39,12 @@ __global__ __launch_bounds__(SEG_BLOCK) void byte_rle_scan_kernel(
     uint32_t n_runs = 0, status = SEG_OK, last_len = 0;
     uint64_t n_bytes = 0;
     uint64_t out_off = 0;
-    uint32_t run_idx = 0, want_runs = 0xFFFFFFFFu;
+    uint32_t run_idx = 0, want_runs = 0xFFFFFFFFu, prev_len = 0;
     if (EMIT) {
         const SegOffset so = seg_global_offset(t, seg);
         out_off = so.val_off;
         run_idx = so.run_off;
+        prev_len = so.prev_len;
         want_runs = t.seg_count[seg].n_runs;
     } else if (end > len || end < pos) {
         status = SEG_MISALIGNED;
@@ -55,8 +69,18 @@ __global__ __launch_bounds__(SEG_BLOCK) void byte_rle_scan_kernel(
             ByteRun r;
             r.src = src | ((uint64_t)(n - 1) << 40);
             r.out_off = out_off;
-            runs[run_idx++] = r;
+            runs[run_idx] = r;
+            const uint64_t win = out_off >> BR_WINDOW_SHIFT;
+            const bool first = out_off == 0 || ((out_off - prev_len) >> BR_WINDOW_SHIFT) != win;
+            if (first && win < n_win_slots) win_first[win] = run_idx;
+            // a window this run covers entirely without starting in it
+            const uint64_t cov = win + 1;
+            if ((out_off & (BR_WINDOW - 1)) != 0 && ((cov + 1) << BR_WINDOW_SHIFT) <= out_off + n &&
+                cov < n_win_slots)
+                win_first[cov] = run_idx + 1;
+            run_idx++;
             out_off += n;
+            prev_len = n;
         }
         n_runs++;
         n_bytes += n;
@@ -66,94 +90,287 @@ __global__ __launch_bounds__(SEG_BLOCK) void byte_rle_scan_kernel(
     if (!EMIT) {
         if (status == SEG_OK && pos != end && !last_seg) status = SEG_MISALIGNED;
         seg_publish(t, seg, n_seg, n_runs, last_len, status, n_bytes);
+    } else if (last_seg) {
+        ByteRun r;  // sentinel: an empty literal one past the end
+        r.src = 0;
+        r.out_off = out_off;
+        runs[run_idx] = r;
+        uint64_t w = out_off == 0 ? 0 : ((out_off - prev_len) >> BR_WINDOW_SHIFT) + 1;
+        const uint64_t w_end = (out_off + BR_WINDOW - 1) >> BR_WINDOW_SHIFT;
+        for (; w <= w_end && w < n_win_slots; w++) win_first[w] = run_idx;
     }
 }
 
-// One lane per run copies the run's bytes (at most 130).
-__global__ __launch_bounds__(256) void byte_rle_expand_kernel(const uint8_t *__restrict__ s,
-                                                              const ByteRun *__restrict__ runs,
-                                                              uint64_t n_runs, uint64_t num_bytes,
-                                                              uint8_t *__restrict__ out) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_runs) return;
-    const ByteRun run = runs[r];
-    if (run.out_off >= num_bytes) return;
-    const uint64_t src = run.src & PAYLOAD_MASK;
-    uint32_t n = (uint32_t)((run.src >> 40) & 0xFF) + 1;
-    if (run.out_off + n > num_bytes) n = (uint32_t)(num_bytes - run.out_off);
-    uint8_t *dst = out + run.out_off;
-    if (run.src & BR_IS_RUN) {
-        const uint8_t v = s[src];
-        for (uint32_t i = 0; i < n; i++) dst[i] = v;
-    } else {
-        for (uint32_t i = 0; i < n; i++) dst[i] = s[src + i];
-    }
+__device__ __forceinline__ uint64_t readfirst_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
 }
 
-// Packed bytes -> one byte per value and/or an LSB-first bitmap, plus the number of ones.
-__global__ __launch_bounds__(256) void bool_expand_kernel(const uint8_t *__restrict__ packed,
-                                                          uint64_t num_bits,
-                                                          uint8_t *__restrict__ out_bytes,
-                                                          uint8_t *__restrict__ out_bitmap,
-                                                          unsigned long long *__restrict__ set_bits) {
-    const uint64_t n_bytes = (num_bits + 7) >> 3;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t ones = 0;
-    if (i < n_bytes) {
-        uint32_t b = packed[i];
-        const uint64_t first = i << 3;
-        const uint32_t valid = (num_bits - first) >= 8 ? 8u : (uint32_t)(num_bits - first);
-        b &= (0xFF00u >> valid) & 0xFFu;  // keep the `valid` most significant bits
-        ones = __popc(b);
-        if (out_bitmap) out_bitmap[i] = (uint8_t)(__brev(b) >> 24);
-        if (out_bytes) {
-            // byte k of the word = bit (7 - k) of b
-            uint64_t word = 0;
+__device__ __forceinline__ uint32_t byte_run_len(const ByteRun &r) {
+    return (uint32_t)((r.src >> 40) & 0xFF) + 1;
+}
+
+// Walks a lane through the run table: find(o) positions it at or shortly before the run that
+// holds decoded byte o, byte_at(pos) returns decoded byte pos for ascending pos >= o.
+struct RunCursor {
+    const uint8_t *s;
+    uint64_t len;
+    const ByteRun *runs;
+    uint32_t n_runs;
+    uint32_t r;
+    ByteRun run;
+
+    __device__ __forceinline__ void find(const uint32_t *__restrict__ win_first, uint64_t o) {
+        // the run before the first one that starts in o's window began before the window; the
+        // few runs between it and o are walked by byte_at
+        r = win_first[o >> BR_WINDOW_SHIFT];
+        if (r > n_runs) r = n_runs;
+        r = r > 0 ? r - 1 : 0;
+        run = runs[r];
+    }
+    // Stream bytes are fetched as aligned dwords (a byte-sized load costs the memory pipeline as
+    // much per lane as a dword-sized one, and consecutive literals share a dword): the last one
+    // is kept.  The aligned dword around a valid byte never leaves the byte's own page.
+    uintptr_t word_addr;
+    uint32_t word;
+
+    __device__ __forceinline__ uint32_t byte_at(uint64_t pos) {
+        // (the scan found all wanted bytes in the runs, so r stays below n_runs)
+        while (r < n_runs && pos >= run.out_off + byte_run_len(run)) run = runs[++r];
+        const uint64_t src = (run.src & PAYLOAD_MASK) + ((run.src & BR_IS_RUN) ? 0 : pos - run.out_off);
+        if (!(r < n_runs && src < len)) return 0u;
+        const uintptr_t a = (uintptr_t)(s + src), aw = a & ~(uintptr_t)3;
+        if (aw != word_addr) {
+            word = *(const uint32_t *)aw;
+            word_addr = aw;
+        }
+        return (word >> (8 * (uint32_t)(a & 3))) & 0xFFu;
+    }
+};
+
+// Bytes: one lane per 16 consecutive decoded bytes, one 16-byte store each.
+__global__ __launch_bounds__(256) void byte_rle_expand_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const ByteRun *__restrict__ runs,
+    const uint32_t *__restrict__ win_first, uint32_t n_runs, uint64_t num_bytes,
+    uint8_t *__restrict__ out) {
+    const uint64_t n_lanes = (num_bytes + 15) / 16;
+    RunCursor cur = {s, len, runs, n_runs, 0, {0, 0}, 0, 0};
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_lanes;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t o = t * 16;
+        cur.find(win_first, o);
+        uint32_t d[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 8; k++) word |= (uint64_t)((b >> (7 - k)) & 1u) << (8 * k);
-            uint8_t *dst = out_bytes + first;
-            if (valid == 8 && (((uintptr_t)dst) & 7) == 0) {
-                *(uint64_t *)dst = word;
-            } else {
-                for (uint32_t k = 0; k < valid; k++) dst[k] = (uint8_t)(word >> (8 * k));
+        for (uint32_t k = 0; k < 16; k++)
+            if (o + k < num_bytes) d[k >> 2] |= cur.byte_at(o + k) << (8 * (k & 3));
+        uint8_t *dst = out + o;
+        if (o + 16 <= num_bytes && (((uintptr_t)dst) & 15) == 0) {
+            *(uint4 *)dst = make_uint4(d[0], d[1], d[2], d[3]);
+        } else {
+            for (uint32_t k = 0; k < 16 && o + k < num_bytes; k++) dst[k] = (uint8_t)(d[k >> 2] >> (8 * (k & 3)));
+        }
+    }
+}
+
+// Stream byte at offset src (src < len), fetched as the aligned dword around it.
+__device__ __forceinline__ uint32_t stream_byte(const uint8_t *s, uint64_t src, uintptr_t &word_addr,
+                                                uint32_t &word) {
+    const uintptr_t a = (uintptr_t)(s + src), aw = a & ~(uintptr_t)3;
+    if (aw != word_addr) {
+        word = *(const uint32_t *)aw;
+        word_addr = aw;
+    }
+    return (word >> (8 * (uint32_t)(a & 3))) & 0xFFu;
+}
+
+// Booleans: every decoded byte is 8 values, most significant bit first (boolean_rle.rs:98,118).
+// A wavefront takes a tile of 512 decoded bytes in 4 steps; in a step lane i owns bytes
+// 128*step + 2*i and the next one, i.e. 16 values, so that each store instruction writes 1 KiB of
+// consecutive values.  The runs that overlap the tile are loaded once, one per lane, and every
+// lane then finds the runs of its bytes with register shuffles (a tile overlapped by more than 64
+// runs falls back to per-lane walks of the run table).  out_bytes: one byte per value;
+// out_bitmap: the same bits least-significant-first; *set_bits: the number of ones.
+__global__ __launch_bounds__(256) void bool_expand_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const ByteRun *__restrict__ runs,
+    const uint32_t *__restrict__ win_first, uint32_t n_win_slots, uint32_t n_runs,
+    uint64_t num_bits, uint8_t *__restrict__ out_bytes, uint8_t *__restrict__ out_bitmap,
+    unsigned long long *__restrict__ set_bits) {
+    const uint64_t num_bytes = (num_bits + 7) >> 3;  // decoded bytes wanted
+    const uint64_t n_tiles = (num_bytes + 511) / 512;
+    const uint32_t lane = threadIdx.x & 63;
+    const bool bytes_aligned = (((uintptr_t)out_bytes) & 15) == 0;
+    const bool bitmap_aligned = (((uintptr_t)out_bitmap) & 1) == 0;
+    uint32_t ones = 0;
+    // grid-stride over tiles: the count of ones costs one atomic per wavefront
+    for (uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles;
+         tile += (uint64_t)gridDim.x * 4) {
+        const uint64_t tile_base = tile * 512;
+        // runs [r_lo, r_hi) overlap the tile: from the one that reaches into its first window to
+        // the last one that starts before its end
+        const uint64_t w0 = tile_base >> BR_WINDOW_SHIFT;
+        const uint64_t w1 = (w0 + 4 < n_win_slots) ? w0 + 4 : n_win_slots - 1;
+        uint32_t r_lo = __builtin_amdgcn_readfirstlane(win_first[w0]);
+        uint32_t r_hi = __builtin_amdgcn_readfirstlane(win_first[w1]);
+        if (r_hi > n_runs) r_hi = n_runs;
+        r_lo = r_lo > 0 ? r_lo - 1 : 0;
+        if (r_lo > r_hi) r_lo = r_hi;
+        // a tile whose 4096 values are all wanted needs no masking of a partial last byte
+        const bool full = (tile_base + 512) * 8 <= num_bits;
+        uint32_t mm[4];  // per step: this lane's two decoded bytes, the first in bits 0..7
+        if (r_hi - r_lo <= 64) {
+            // lane k holds run r_lo + k: its start relative to the tile (negative for a run that
+            // began before it) and its source relative to the first run's
+            int32_t my_rel = 0x7FFFFFFF;
+            uint64_t my_src = 0;
+            if (lane < r_hi - r_lo) {
+                const ByteRun run = runs[r_lo + lane];
+                my_rel = (int32_t)(int64_t)(run.out_off - tile_base);
+                my_src = run.src;
+            }
+            const uint64_t src0 = readfirst_u64(my_src) & PAYLOAD_MASK;
+            // offset from src0 (runs of one tile lie within 64 * 131 stream bytes), run flag on top
+            const uint32_t my_srel = (uint32_t)((my_src & PAYLOAD_MASK) - src0) |
+                                     ((my_src & BR_IS_RUN) ? 0x80000000u : 0u);
+            // all addressing below is 32-bit, relative to the aligned dword at or before s + src0
+            const uint8_t *sb = s + src0;
+            const uint32_t skew = (uint32_t)((uintptr_t)sb & 3);
+            const uint32_t *sw = (const uint32_t *)(sb - skew);
+            const uint64_t avail = len > src0 ? len - src0 : 0;  // stream bytes from src0 on
+            const uint32_t lim = avail > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)avail;
+            uint32_t word_idx = 0xFFFFFFFFu, word = 0;
+#pragma unroll
+            for (uint32_t step = 0; step < 4; step++) {
+                const int32_t p = (int32_t)(128 * step + 2 * lane);
+                // largest k with rel[k] <= p (lanes past the last run hold INT_MAX; rel[0] <= 0)
+                int k = 0;
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) {
+                    const int32_t v = __shfl(my_rel, k + sft);
+                    if (v <= p) k += sft;
+                }
+                const int32_t rel_k = __shfl(my_rel, k);
+                int32_t rel_n = __shfl(my_rel, (k + 1) & 63);
+                if (k == 63) rel_n = 0x7FFFFFFF;  // no run after the 64th
+                const uint32_t srel_k = __shfl(my_srel, k), srel_n = __shfl(my_srel, (k + 1) & 63);
+                uint32_t two = 0;
+#pragma unroll
+                for (uint32_t h = 0; h < 2; h++) {
+                    const int32_t q = p + (int32_t)h;
+                    const bool next = q >= rel_n;  // runs are not empty: the next byte is in k or k + 1
+                    const uint32_t srel = next ? srel_n : srel_k;
+                    const int32_t rel = next ? rel_n : rel_k;
+                    const uint32_t off = (srel & 0x7FFFFFFFu) + ((srel >> 31) ? 0u : (uint32_t)(q - rel));
+                    const uint32_t boff = off + skew;
+                    if (off < lim && (boff >> 2) != word_idx) {
+                        word_idx = boff >> 2;
+                        word = sw[word_idx];
+                    }
+                    const uint32_t byte = off < lim ? (word >> (8 * (boff & 3))) & 0xFFu : 0u;
+                    two |= byte << (8 * h);
+                }
+                mm[step] = two;
+            }
+        } else {
+            RunCursor cur = {s, len, runs, n_runs, 0, {0, 0}, 0, 0};
+            for (uint32_t step = 0; step < 4; step++) {
+                const uint64_t o = tile_base + 128 * step + 2 * lane;
+                mm[step] = 0;
+                if (o < num_bytes) {
+                    cur.find(win_first, o);
+                    mm[step] = cur.byte_at(o);
+                    if (o + 1 < num_bytes) mm[step] |= cur.byte_at(o + 1) << 8;
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t step = 0; step < 4; step++) {
+            const uint64_t o = tile_base + 128 * step + 2 * lane;
+            uint32_t two = mm[step];
+            if (!full) {
+                if (o >= num_bytes) break;
+                // clear the bytes and bits past the last value
+                const uint64_t first = o << 3;
+                const uint64_t left = num_bits - first;  // > 0: o < num_bytes
+                if (left < 16) two &= left <= 8 ? ((0xFF00u >> left) & 0xFFu) : (0xFFu | (((0xFF00u >> (left - 8)) & 0xFFu) << 8));
+            }
+            ones += __popc(two);
+            if (out_bitmap) {
+                const uint32_t lsb = __brev(two) >> 16;          // both bytes bit-reversed, swapped
+                const uint32_t bm = ((lsb >> 8) | (lsb << 8)) & 0xFFFFu;
+                uint8_t *dst = out_bitmap + o;
+                if ((full || o + 2 <= num_bytes) && bitmap_aligned) {
+                    *(uint16_t *)dst = (uint16_t)bm;
+                } else {
+                    dst[0] = (uint8_t)bm;
+                    if (o + 1 < num_bytes) dst[1] = (uint8_t)(bm >> 8);
+                }
+            }
+            if (out_bytes) {
+                uint64_t word[2];
+#pragma unroll
+                for (uint32_t k = 0; k < 2; k++) {  // byte j of the word = bit (7 - j) of the decoded byte
+                    // replicate the byte, keep one bit per copy, turn "non-zero" into 1
+                    const uint32_t rep = ((two >> (8 * k)) & 0xFFu) * 0x01010101u;
+                    const uint32_t lo4 = (((rep & 0x10204080u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u;
+                    const uint32_t hi4 = (((rep & 0x01020408u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u;
+                    word[k] = ((uint64_t)hi4 << 32) | lo4;
+                }
+                const uint64_t first = o << 3;
+                uint8_t *dst = out_bytes + first;
+                if ((full || first + 16 <= num_bits) && bytes_aligned) {
+                    *(ulonglong2 *)dst = make_ulonglong2(word[0], word[1]);
+                } else {
+                    for (uint32_t j = 0; j < 16 && first + j < num_bits; j++)
+                        dst[j] = (uint8_t)(word[j >> 3] >> (8 * (j & 7)));
+                }
             }
         }
     }
     if (set_bits) {
+        // every lane of the wavefront is here, those without work carrying 0
         for (int d = 32; d >= 1; d >>= 1) ones += __shfl_down(ones, d);
-        if ((threadIdx.x & 63) == 0 && ones) atomicAdd(set_bits, (unsigned long long)ones);
+        if (lane == 0 && ones) atomicAdd(set_bits, (unsigned long long)ones);
     }
 }
+
+constexpr uint64_t BR_MAX_BLOCKS = 256 * 16;  // workgroups of the expansion: 16 per CU
 
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                                  const uint64_t *entries, uint32_t n_seg, const SegTable &t) {
     byte_rle_scan_kernel<false><<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(
-        stream, len, entries, n_seg, t, nullptr);
+        stream, len, entries, n_seg, t, nullptr, nullptr, 0);
     return hipGetLastError();
 }
 
 hipError_t launch_byte_rle_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                                 const uint64_t *entries, uint32_t n_seg, const SegTable &t,
-                                ByteRun *runs) {
+                                ByteRun *runs, uint32_t *win_first, uint32_t n_win_slots) {
     byte_rle_scan_kernel<true><<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(
-        stream, len, entries, n_seg, t, runs);
+        stream, len, entries, n_seg, t, runs, win_first, n_win_slots);
     return hipGetLastError();
 }
 
-hipError_t launch_byte_rle_expand(hipStream_t st, const uint8_t *stream, const ByteRun *runs,
-                                  uint64_t n_runs, uint64_t num_bytes, uint8_t *out) {
-    if (n_runs == 0) return hipSuccess;
-    byte_rle_expand_kernel<<<(uint32_t)((n_runs + 255) / 256), 256, 0, st>>>(stream, runs, n_runs,
-                                                                            num_bytes, out);
+hipError_t launch_byte_rle_expand(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                  const ByteRun *runs, const uint32_t *win_first, uint32_t n_runs,
+                                  uint64_t num_bytes, uint8_t *out) {
+    if (num_bytes == 0) return hipSuccess;
+    const uint64_t lanes = (num_bytes + 15) / 16;
+    byte_rle_expand_kernel<<<(uint32_t)std::min<uint64_t>((lanes + 255) / 256, BR_MAX_BLOCKS), 256, 0, st>>>(
+        stream, len, runs, win_first, n_runs, num_bytes, out);
     return hipGetLastError();
 }
 
-hipError_t launch_bool_expand(hipStream_t st, const uint8_t *packed, uint64_t num_bits,
-                              uint8_t *out_bytes, uint8_t *out_bitmap, uint64_t *set_bits) {
+hipError_t launch_bool_expand(hipStream_t st, const uint8_t *stream, uint64_t len,
+                              const ByteRun *runs, const uint32_t *win_first, uint32_t n_win_slots,
+                              uint32_t n_runs, uint64_t num_bits, uint8_t *out_bytes,
+                              uint8_t *out_bitmap, uint64_t *set_bits) {
     const uint64_t n_bytes = (num_bits + 7) >> 3;
     if (n_bytes == 0) return hipSuccess;
-    bool_expand_kernel<<<(uint32_t)((n_bytes + 255) / 256), 256, 0, st>>>(
-        packed, num_bits, out_bytes, out_bitmap, (unsigned long long *)set_bits);
+    const uint64_t tiles = (n_bytes + 511) / 512;  // one per wavefront, four per workgroup
+    bool_expand_kernel<<<(uint32_t)std::min<uint64_t>((tiles + 3) / 4, BR_MAX_BLOCKS), 256, 0, st>>>(
+        stream, len, runs, win_first, n_win_slots, n_runs, num_bits, out_bytes, out_bitmap,
+        (unsigned long long *)set_bits);
     return hipGetLastError();
 }
 

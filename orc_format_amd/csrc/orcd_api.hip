@@ -194,26 +194,48 @@ int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_va
     return ORCD_OK;
 }
 
-// Byte-RLE decode with device-side input and output.
-int byte_rle_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_bytes,
-                    const uint64_t *d_entries, size_t n_entries, uint8_t *d_out) {
+struct ByteRleTable {
+    const ByteRun *runs;
+    const uint32_t *win_first;
+    uint32_t n_win_slots;
+    uint32_t n_runs;
+};
+
+// Builds the run table of one byte-RLE stream that is already on the device.
+int byte_rle_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_bytes,
+                   const uint64_t *d_entries, size_t n_entries, ByteRleTable *t) {
     if (n_entries > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
     ScanResult sr;
-    ORCD_TRY(count_and_scan(c, n_seg, num_bytes, [&](const SegTable &t) {
-        return launch_byte_rle_count(c->stream, d_stream, len, entries, n_seg, t);
+    ORCD_TRY(count_and_scan(c, n_seg, num_bytes, [&](const SegTable &st) {
+        return launch_byte_rle_count(c->stream, d_stream, len, entries, n_seg, st);
     }, &sr));
     mark(c, 1);
     if (sr.totals.error) return (int)sr.totals.error;
     if (sr.totals.total_runs >= 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
-    void *runs;
+    const size_t n_slots = byte_rle_window_slots(sr.totals.total_vals);
+    if (n_slots > 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
+    void *runs, *wins;
     ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(ByteRun), &runs));
+    ORCD_TRY(ensure(c, SLOT_GROUPS, n_slots * sizeof(uint32_t), &wins));
     HIP_TRY(c, launch_byte_rle_emit(c->stream, d_stream, len, entries, n_seg, sr.table,
-                                    (ByteRun *)runs));
+                                    (ByteRun *)runs, (uint32_t *)wins, (uint32_t)n_slots));
     mark(c, 2);
-    HIP_TRY(c, launch_byte_rle_expand(c->stream, d_stream, (const ByteRun *)runs,
-                                      sr.totals.total_runs, num_bytes, d_out));
+    t->runs = (const ByteRun *)runs;
+    t->win_first = (const uint32_t *)wins;
+    t->n_win_slots = (uint32_t)n_slots;
+    t->n_runs = (uint32_t)sr.totals.total_runs;
+    return ORCD_OK;
+}
+
+// Byte-RLE decode with device-side input and output.
+int byte_rle_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_bytes,
+                    const uint64_t *d_entries, size_t n_entries, uint8_t *d_out) {
+    ByteRleTable t;
+    ORCD_TRY(byte_rle_table(c, d_stream, len, num_bytes, d_entries, n_entries, &t));
+    HIP_TRY(c, launch_byte_rle_expand(c->stream, d_stream, len, t.runs, t.win_first, t.n_runs,
+                                      num_bytes, d_out));
     mark(c, 3);
     return ORCD_OK;
 }
@@ -442,11 +464,11 @@ int orcd_boolean_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t n
     const void *d_stream, *d_entries;
     ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
     ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t), in_dev, &d_entries));
-    void *packed, *flagbuf;
-    ORCD_TRY(ensure(c, SLOT_PACKED, n_bytes, &packed));
+    void *flagbuf;
     ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flagbuf));
-    ORCD_TRY(byte_rle_device(c, (const uint8_t *)d_stream, len, n_bytes, (const uint64_t *)d_entries,
-                             n_entries, (uint8_t *)packed));
+    ByteRleTable t;
+    ORCD_TRY(byte_rle_table(c, (const uint8_t *)d_stream, len, n_bytes, (const uint64_t *)d_entries,
+                            n_entries, &t));
     uint8_t *d_bytes = out_bytes, *d_bitmap = out_bitmap;
     if (!out_dev) {
         void *p;
@@ -461,8 +483,10 @@ int orcd_boolean_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t n
     }
     uint64_t *d_count = set_bits ? (uint64_t *)flagbuf : nullptr;
     if (d_count) HIP_TRY(c, hipMemsetAsync(d_count, 0, sizeof(uint64_t), c->stream));
+    // the run table expands straight into values: no packed intermediate
     if (d_bytes || d_bitmap || d_count)
-        HIP_TRY(c, launch_bool_expand(c->stream, (const uint8_t *)packed, num_bits, d_bytes, d_bitmap, d_count));
+        HIP_TRY(c, launch_bool_expand(c->stream, (const uint8_t *)d_stream, len, t.runs, t.win_first,
+                                      t.n_win_slots, t.n_runs, num_bits, d_bytes, d_bitmap, d_count));
     mark(c, 3);
     if (d_count)
         HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_count, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));

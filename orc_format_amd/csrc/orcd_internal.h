@@ -126,11 +126,18 @@ hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t
                                  const uint64_t *entries, uint32_t n_seg, const SegTable &t);
 hipError_t launch_byte_rle_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                                 const uint64_t *entries, uint32_t n_seg, const SegTable &t,
-                                ByteRun *runs);
-hipError_t launch_byte_rle_expand(hipStream_t st, const uint8_t *stream, const ByteRun *runs,
-                                  uint64_t n_runs, uint64_t num_bytes, uint8_t *out);
-hipError_t launch_bool_expand(hipStream_t st, const uint8_t *packed, uint64_t num_bits,
-                              uint8_t *out_bytes, uint8_t *out_bitmap, uint64_t *set_bits);
+                                ByteRun *runs, uint32_t *win_first, uint32_t n_win_slots);
+// slots of win_first for a stream of total_bytes decoded bytes
+size_t byte_rle_window_slots(uint64_t total_bytes);
+hipError_t launch_byte_rle_expand(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                  const ByteRun *runs, const uint32_t *win_first, uint32_t n_runs,
+                                  uint64_t num_bytes, uint8_t *out);
+// run table -> booleans in one pass: one byte per value, and/or an LSB-first bitmap, plus the
+// number of ones (set_bits must be zeroed beforehand)
+hipError_t launch_bool_expand(hipStream_t st, const uint8_t *stream, uint64_t len,
+                              const ByteRun *runs, const uint32_t *win_first, uint32_t n_win_slots,
+                              uint32_t n_runs, uint64_t num_bits, uint8_t *out_bytes,
+                              uint8_t *out_bitmap, uint64_t *set_bits);
 
 // In-place exclusive prefix sum of n 64-bit values; data[n] receives the total.
 // `block_sums` needs room for scan_block_sums_len(n) values.  A value above `limit` (which must
