@@ -49,7 +49,9 @@ enum {
     ORCD_SIGNED = 1u,      /* RLE v2: zigzag-decode values (SignedRleV2Iter) */
     ORCD_IN_DEVICE = 2u,   /* stream / entry-point pointers are device memory */
     ORCD_OUT_DEVICE = 4u,  /* output pointers are device memory */
-    ORCD_CHECK_UTF8 = 8u   /* strings: validate each value (tests/it/deserialize.rs:116-118) */
+    ORCD_CHECK_UTF8 = 8u,  /* strings: validate each value (tests/it/deserialize.rs:116-118) */
+    ORCD_SCATTER_CARRY = 16u, /* orcd_scatter_valid: null rows repeat the next value (offsets) */
+    ORCD_ROW_ALIGNED = 32u /* orcd_decode_column: one slot per row instead of per non-null row */
 };
 
 /* ---- stream kinds (src/proto.rs:127-136) and column encodings (src/proto.rs:149-154) -------- */
@@ -232,6 +234,50 @@ uint64_t orcd_column_number_of_rows(const orcd_column *column);
  * offsets for stream `kind`. */
 int orcd_column_entry_points(orcd_file *file, orcd_column *column, int kind,
                              const uint64_t **entries, size_t *n_entries);
+
+/* ---- null scatter and whole columns ------------------------------------------------------------ */
+
+/* Dense non-null values -> one slot per row.  The crate's harness stops at (validity, dense
+ * values) (tests/it/deserialize.rs:48-82: the values are not moved to their rows); this is the
+ * step a columnar consumer adds on top.  `validity` has num_rows bytes (non-zero = valid, the
+ * out_bytes of orcd_boolean_decode), `dense` has num_values entries of elem_size (1, 4 or 8)
+ * bytes, `out` receives num_rows entries: out[r] = dense[number of valid rows before r] for valid
+ * rows and zero for null rows.  With ORCD_SCATTER_CARRY null rows receive that dense entry too and
+ * `dense` has num_values + 1 entries: string offsets scattered this way give every null row an
+ * empty value.  The number of valid rows must equal num_values (else ORCD_INVALID_ARGUMENT).
+ * All three pointers follow ORCD_IN_DEVICE (validity, dense) / ORCD_OUT_DEVICE (out). */
+int orcd_scatter_valid(orcd_ctx *ctx, const uint8_t *validity, size_t num_rows, const void *dense,
+                       size_t num_values, size_t elem_size, void *out, unsigned flags);
+
+/* One column of one stripe, decoded: what the deserialize_* functions of the crate's harness return
+ * (tests/it/deserialize.rs:13-222), for the column's ORC type.  Arrays are owned by the structure
+ * (release with orcd_column_data_free) and live in host memory, or in device memory when the call
+ * had ORCD_OUT_DEVICE. */
+typedef struct {
+    int type_kind;        /* proto Type.Kind of the column (src/proto.rs:181-203) */
+    int on_device;        /* where the arrays below live */
+    int row_aligned;      /* ORCD_ROW_ALIGNED was applied */
+    uint64_t num_rows;    /* rows of the stripe = entries of `validity` */
+    uint64_t num_values;  /* non-null rows */
+    uint64_t num_slots;   /* entries of `values` / of `offsets` minus one: num_values, or num_rows when row-aligned */
+    uint8_t *validity;    /* [num_rows] 0 / 1 (Vec<bool>); all 1 when the column has no PRESENT stream */
+    void *values;         /* SHORT / INT / LONG / DATE: int64; FLOAT: f32; DOUBLE: f64; BOOLEAN, BYTE: one byte; strings: NULL */
+    size_t value_size;    /* bytes per entry of `values` (0 for strings) */
+    int64_t *offsets;     /* STRING / VARCHAR / CHAR / BINARY: [num_slots + 1] offsets into `bytes` */
+    uint8_t *bytes;       /* the values' bytes, concatenated */
+    uint64_t num_bytes;
+} orcd_column_data;
+
+/* Reads column `column` of stripe `stripe` (one seek, one read, as read_stripe_column), finds its
+ * streams and ROW_INDEX entry points and runs the decoders above.  Flags: ORCD_OUT_DEVICE,
+ * ORCD_CHECK_UTF8 (STRING / VARCHAR / CHAR), ORCD_ROW_ALIGNED.  Departures from the harness, both
+ * where the harness departs from the format: a column without PRESENT stream is all valid
+ * (deserialize.rs:14 returns InvalidKind), a dictionary column holds one index per non-null row
+ * (deserialize.rs:160 uses the row count).  Unsupported types yield ORCD_UNSUPPORTED. */
+int orcd_decode_column(orcd_ctx *ctx, orcd_file *file, size_t stripe,
+                       const orcd_stripe_footer *footer, uint32_t column, unsigned flags,
+                       orcd_column_data *out);
+void orcd_column_data_free(orcd_column_data *data);
 
 #ifdef __cplusplus
 }

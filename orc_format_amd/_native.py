@@ -13,7 +13,7 @@ OK, OUT_OF_SPEC, INVALID_UTF8, INVALID_COLUMN, INVALID_KIND, DECODE_FLOAT, DECOM
     INVALID_PROTO = range(8)
 UNSUPPORTED, HIP_ERROR, INVALID_ARGUMENT = 100, 101, 102
 
-SIGNED, IN_DEVICE, OUT_DEVICE, CHECK_UTF8 = 1, 2, 4, 8
+SIGNED, IN_DEVICE, OUT_DEVICE, CHECK_UTF8, SCATTER_CARRY, ROW_ALIGNED = 1, 2, 4, 8, 16, 32
 
 
 class OrcdRun(C.Structure):
@@ -29,6 +29,13 @@ class StripeInfo(C.Structure):
 class StreamInfo(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("column", C.c_uint32), ("length", C.c_uint64),
                 ("offset", C.c_uint64)]
+
+
+class ColumnData(C.Structure):
+    _fields_ = [("type_kind", C.c_int), ("on_device", C.c_int), ("row_aligned", C.c_int),
+                ("num_rows", C.c_uint64), ("num_values", C.c_uint64), ("num_slots", C.c_uint64),
+                ("validity", C.c_void_p), ("values", C.c_void_p), ("value_size", C.c_size_t),
+                ("offsets", C.c_void_p), ("bytes", C.c_void_p), ("num_bytes", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/orcd.h declares
@@ -71,6 +78,9 @@ SIGNATURES = {
     "orcd_column_encoding": (C.c_int, [P, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "orcd_column_number_of_rows": (C.c_uint64, [P]),
     "orcd_column_entry_points": (C.c_int, [P, P, C.c_int, C.POINTER(P), C.POINTER(SZ)]),
+    "orcd_scatter_valid": (C.c_int, [P, P, SZ, P, SZ, SZ, P, C.c_uint]),
+    "orcd_decode_column": (C.c_int, [P, P, SZ, P, C.c_uint32, C.c_uint, C.POINTER(ColumnData)]),
+    "orcd_column_data_free": (None, [C.POINTER(ColumnData)]),
 }
 
 _lib = None

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liborcd.so")
-SOURCES = ["rlev2.hip", "byte_rle.hip", "strings.hip", "orcd_api.hip", "orcd_host.cpp"]
+SOURCES = ["rlev2.hip", "byte_rle.hip", "strings.hip", "scatter.hip", "orcd_api.hip", "orcd_host.cpp"]
 HEADERS = ["orcd_internal.h", "seg_scan.h", os.path.join("..", "..", "include", "orcd.h")]
 
 

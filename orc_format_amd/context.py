@@ -148,6 +148,44 @@ class Context:
         check(rc, self._h)
         return offsets, out[:offsets[n]]
 
+    def scatter_valid(self, validity, dense, carry=False):
+        """Dense non-null values -> one slot per row (zeros, or with `carry` the next value, at
+        null rows)."""
+        v = np.ascontiguousarray(validity).view(np.uint8)
+        d = np.ascontiguousarray(dense)
+        n_values = d.size - (1 if carry else 0)
+        out = np.empty(v.size, dtype=d.dtype)
+        rc = self._lib.orcd_scatter_valid(self._h, v.ctypes.data, v.size, d.ctypes.data, n_values,
+                                          d.itemsize, out.ctypes.data, N.SCATTER_CARRY if carry else 0)
+        check(rc, self._h)
+        return out
+
+    def decode_column(self, metadata, stripe, footer, column, check_utf8=True, row_aligned=False):
+        """One column of one stripe through orcd_decode_column (host results).  Returns a dict:
+        type_kind, validity (bool[num_rows]), and `values` (numpy) or `offsets` + `bytes`."""
+        cd = N.ColumnData()
+        flags = (N.CHECK_UTF8 if check_utf8 else 0) | (N.ROW_ALIGNED if row_aligned else 0)
+        check(self._lib.orcd_decode_column(self._h, metadata._h, stripe, footer._h, column, flags,
+                                           C.byref(cd)), self._h)
+        try:
+            def arr(ptr, count, dtype):
+                if count == 0:
+                    return np.empty(0, dtype=dtype)
+                buf = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+                return np.frombuffer(buf, dtype=dtype).copy()
+            out = {"type_kind": cd.type_kind, "num_values": cd.num_values,
+                   "validity": arr(cd.validity, cd.num_rows, np.uint8).astype(bool)}
+            if cd.values:
+                dtype = {(5, 4): np.float32, (6, 8): np.float64}.get(
+                    (cd.type_kind, cd.value_size), {8: np.int64, 1: np.uint8}.get(cd.value_size))
+                out["values"] = arr(cd.values, cd.num_slots, dtype)
+            if cd.offsets:
+                out["offsets"] = arr(cd.offsets, cd.num_slots + 1, np.int64)
+                out["bytes"] = arr(cd.bytes, cd.num_bytes, np.uint8) if cd.bytes else np.empty(0, np.uint8)
+            return out
+        finally:
+            self._lib.orcd_column_data_free(C.byref(cd))
+
     # ---- device-pointer calls (raw addresses) -------------------------------------------------
     def rlev2_device(self, stream_ptr, length, num_values, signed, out_ptr, entries_ptr=0,
                      n_entries=0):

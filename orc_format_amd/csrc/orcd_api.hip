@@ -1,9 +1,11 @@
 // C ABI of the decoder: context (stream, events, recycled device buffers) and the decode entry
 // points, which validate arguments, move host buffers when asked to, and chain the kernels.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "orcd_internal.h"
 #include "seg_scan.h"
@@ -708,6 +710,317 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return ORCD_OK;
+}
+
+// ---- null scatter ---------------------------------------------------------------------------
+
+namespace {
+
+// Device-side scatter; validity, dense and out are device pointers.
+int scatter_device(orcd_ctx *c, const uint8_t *d_validity, size_t num_rows, const void *d_dense,
+                   size_t num_values, size_t elem_size, void *d_out, bool carry) {
+    const size_t tiles = scatter_tiles(num_rows);
+    void *counts, *sums;
+    ORCD_TRY(ensure(c, SLOT_TMP, (tiles + 1) * sizeof(uint64_t), &counts));
+    ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(tiles) * sizeof(uint64_t), &sums));
+    void *flag;
+    ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
+    HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, launch_valid_count(c->stream, d_validity, num_rows, (uint64_t *)counts));
+    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)counts, tiles, (uint64_t *)sums,
+                                         SC_MAX_TILE_COUNT, (uint32_t *)flag));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, (uint64_t *)counts + tiles, sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_scalars[0] != num_values) return ORCD_INVALID_ARGUMENT;
+    HIP_TRY(c, launch_scatter_valid(c->stream, d_validity, num_rows, (const uint64_t *)counts, d_dense,
+                                    num_values + (carry ? 1 : 0), elem_size, d_out, carry));
+    return ORCD_OK;
+}
+
+}  // namespace
+
+int orcd_scatter_valid(orcd_ctx *c, const uint8_t *validity, size_t num_rows, const void *dense,
+                       size_t num_values, size_t elem_size, void *out, unsigned flags) {
+    if (!c || (num_rows && (!validity || !out)) || (num_values && !dense)) return ORCD_INVALID_ARGUMENT;
+    if (elem_size != 1 && elem_size != 4 && elem_size != 8) return ORCD_INVALID_ARGUMENT;
+    const bool carry = flags & ORCD_SCATTER_CARRY;
+    if (carry && !dense) return ORCD_INVALID_ARGUMENT;
+    if (num_rows == 0) return num_values == 0 ? ORCD_OK : ORCD_INVALID_ARGUMENT;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    mark(c, 0);
+    const void *d_validity, *d_dense;
+    ORCD_TRY(stage_in(c, SLOT_IN_A, validity, num_rows, in_dev, &d_validity));
+    ORCD_TRY(stage_in(c, SLOT_IN_B, dense, (num_values + (carry ? 1 : 0)) * elem_size, in_dev, &d_dense));
+    void *d_out = out;
+    if (!out_dev) ORCD_TRY(ensure(c, SLOT_OUT_A, num_rows * elem_size, &d_out));
+    ORCD_TRY(scatter_device(c, (const uint8_t *)d_validity, num_rows, d_dense, num_values, elem_size,
+                            d_out, carry));
+    mark(c, 3);
+    if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, num_rows * elem_size));
+    return ORCD_OK;
+}
+
+// ---- whole columns --------------------------------------------------------------------------
+
+namespace {
+
+enum TypeKind {  // proto Type.Kind (src/proto.rs:181-203)
+    T_BOOLEAN = 0, T_BYTE = 1, T_SHORT = 2, T_INT = 3, T_LONG = 4, T_FLOAT = 5, T_DOUBLE = 6,
+    T_STRING = 7, T_BINARY = 8, T_TIMESTAMP = 9, T_LIST = 10, T_MAP = 11, T_STRUCT = 12,
+    T_UNION = 13, T_DECIMAL = 14, T_DATE = 15, T_VARCHAR = 16, T_CHAR = 17
+};
+
+struct ColumnStreams {
+    orcd_file *file;
+    orcd_column *col;
+    // a stream's bytes (empty when absent) and its ROW_INDEX entry points
+    int get(int kind, const uint8_t **bytes, size_t *len, const uint64_t **entries, size_t *n_entries,
+            bool required) const {
+        *bytes = nullptr;
+        *len = 0;
+        *entries = nullptr;
+        *n_entries = 0;
+        const int rc = orcd_column_get_stream(col, kind, bytes, len);
+        if (rc == ORCD_INVALID_KIND && !required) return ORCD_OK;
+        if (rc != ORCD_OK) return rc;
+        return orcd_column_entry_points(file, col, kind, entries, n_entries);
+    }
+};
+
+int dev_alloc(orcd_ctx *c, size_t bytes, void **p) {
+    *p = nullptr;
+    HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16));
+    return ORCD_OK;
+}
+
+// Moves a device result array to where the caller wants it: stays (device) or a malloc'd copy.
+int deliver(orcd_ctx *c, void *d_ptr, size_t bytes, bool out_dev, void **result) {
+    if (out_dev) {
+        *result = d_ptr;
+        return ORCD_OK;
+    }
+    void *h = malloc(bytes ? bytes : 1);
+    if (!h) {
+        (void)hipFree(d_ptr);
+        return ORCD_HIP_ERROR;
+    }
+    hipError_t e = bytes ? hipMemcpyAsync(h, d_ptr, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_ptr);
+    if (e != hipSuccess) {
+        free(h);
+        c->last_hip = e;
+        return ORCD_HIP_ERROR;
+    }
+    *result = h;
+    return ORCD_OK;
+}
+
+// Device arrays of a column under construction; whatever is still set at scope exit is released.
+struct Pending {
+    void *validity = nullptr, *values = nullptr, *offsets = nullptr, *bytes = nullptr, *tmp = nullptr,
+         *tmp2 = nullptr;
+    ~Pending() {
+        for (void *p : {validity, values, offsets, bytes, tmp, tmp2})
+            if (p) (void)hipFree(p);
+    }
+};
+
+int decode_column_impl(orcd_ctx *c, orcd_file *file, orcd_column *col, int type_kind, unsigned flags,
+                       orcd_column_data *out) {
+    const bool out_dev = flags & ORCD_OUT_DEVICE, row_aligned = flags & ORCD_ROW_ALIGNED;
+    const unsigned io = ORCD_OUT_DEVICE;  // streams are host memory, results stay on the device
+    const ColumnStreams cs{file, col};
+    const uint64_t rows = orcd_column_number_of_rows(col);
+    const uint8_t *sb;
+    size_t sl;
+    const uint64_t *ent;
+    size_t n_ent;
+    Pending p;
+
+    // validity (deserialize_validity, deserialize.rs:13-25)
+    uint64_t n_values = rows;
+    ORCD_TRY(dev_alloc(c, rows, &p.validity));
+    ORCD_TRY(cs.get(ORCD_STREAM_PRESENT, &sb, &sl, &ent, &n_ent, false));
+    if (sb) {
+        ORCD_TRY(orcd_boolean_decode(c, sb, sl, rows, ent, n_ent, (uint8_t *)p.validity, nullptr,
+                                     &n_values, io));
+    } else {
+        HIP_TRY(c, hipMemsetAsync(p.validity, 1, rows, c->stream));
+    }
+    const uint64_t slots = row_aligned ? rows : n_values;
+    size_t value_size = 0;
+    uint64_t num_bytes = 0;
+
+    switch (type_kind) {
+    case T_SHORT: case T_INT: case T_LONG: case T_DATE: {  // deserialize_int_array, deserialize.rs:48-82
+        value_size = 8;
+        ORCD_TRY(dev_alloc(c, n_values * 8, &p.values));
+        ORCD_TRY(cs.get(ORCD_STREAM_DATA, &sb, &sl, &ent, &n_ent, n_values != 0));
+        ORCD_TRY(orcd_rlev2_decode(c, sb, sl, n_values, ent, n_ent, (int64_t *)p.values, ORCD_SIGNED | io));
+        break;
+    }
+    case T_BOOLEAN: {  // deserialize_bool_array, deserialize.rs:84-104
+        value_size = 1;
+        ORCD_TRY(dev_alloc(c, n_values, &p.values));
+        ORCD_TRY(cs.get(ORCD_STREAM_DATA, &sb, &sl, &ent, &n_ent, n_values != 0));
+        ORCD_TRY(orcd_boolean_decode(c, sb, sl, n_values, ent, n_ent, (uint8_t *)p.values, nullptr, nullptr, io));
+        break;
+    }
+    case T_BYTE: {
+        value_size = 1;
+        ORCD_TRY(dev_alloc(c, n_values, &p.values));
+        ORCD_TRY(cs.get(ORCD_STREAM_DATA, &sb, &sl, &ent, &n_ent, n_values != 0));
+        ORCD_TRY(orcd_byte_rle_decode(c, sb, sl, n_values, ent, n_ent, (uint8_t *)p.values, io));
+        break;
+    }
+    case T_FLOAT: case T_DOUBLE: {  // deserialize_f32_array, deserialize.rs:27-46
+        value_size = type_kind == T_FLOAT ? 4 : 8;
+        ORCD_TRY(dev_alloc(c, n_values * value_size, &p.values));
+        ORCD_TRY(cs.get(ORCD_STREAM_DATA, &sb, &sl, &ent, &n_ent, n_values != 0));
+        ORCD_TRY(orcd_float_decode(c, sb, sl, value_size, n_values, p.values, io));
+        break;
+    }
+    case T_STRING: case T_VARCHAR: case T_CHAR: case T_BINARY: {  // deserialize_str_array, deserialize.rs:203-222
+        const unsigned utf8 = (type_kind != T_BINARY) ? (flags & ORCD_CHECK_UTF8) : 0u;
+        int enc = 0;
+        uint32_t dict_size = 0;
+        ORCD_TRY(orcd_column_encoding(col, &enc, &dict_size));
+        const uint8_t *lb;
+        size_t ll;
+        const uint64_t *lent;
+        size_t n_lent;
+        ORCD_TRY(dev_alloc(c, (n_values + 1) * 8, &p.offsets));
+        if (enc == ORCD_ENC_DIRECT_V2) {  // deserialize_str_array_direct, deserialize.rs:187-201
+            ORCD_TRY(cs.get(ORCD_STREAM_LENGTH, &lb, &ll, &lent, &n_lent, n_values != 0));
+            ORCD_TRY(cs.get(ORCD_STREAM_DATA, &sb, &sl, &ent, &n_ent, false));
+            ORCD_TRY(dev_alloc(c, sl, &p.bytes));
+            ORCD_TRY(orcd_string_direct_decode(c, lb, ll, lent, n_lent, sb, sl, n_values,
+                                               (int64_t *)p.offsets, (uint8_t *)p.bytes, io | utf8));
+        } else if (enc == ORCD_ENC_DICTIONARY_V2) {  // deserialize_str_dict_array, deserialize.rs:142-185
+            ORCD_TRY(cs.get(ORCD_STREAM_LENGTH, &lb, &ll, &lent, &n_lent, dict_size != 0));
+            ORCD_TRY(cs.get(ORCD_STREAM_DICTIONARY_DATA, &sb, &sl, &ent, &n_ent, false));
+            // the dictionary: offsets[dict_size + 1] and its bytes, on the device
+            ORCD_TRY(dev_alloc(c, ((size_t)dict_size + 1) * 8, &p.tmp));
+            ORCD_TRY(dev_alloc(c, sl, &p.tmp2));
+            // (the LENGTH stream of a dictionary has no ROW_INDEX positions of its own)
+            ORCD_TRY(orcd_string_direct_decode(c, lb, ll, nullptr, 0, sb, sl, dict_size, (int64_t *)p.tmp,
+                                               (uint8_t *)p.tmp2, io | utf8));
+            // longest entry: bounds the bytes of the gathered column
+            std::vector<int64_t> h_off((size_t)dict_size + 1);
+            HIP_TRY(c, hipMemcpyAsync(h_off.data(), p.tmp, h_off.size() * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            int64_t longest = 0;
+            for (size_t i = 0; i < dict_size; i++) longest = std::max(longest, h_off[i + 1] - h_off[i]);
+            // the indices: one per non-null row
+            void *d_idx;
+            ORCD_TRY(ensure(c, SLOT_OUT_B, n_values * 8, &d_idx));
+            const uint8_t *ib;
+            size_t il;
+            ORCD_TRY(cs.get(ORCD_STREAM_DATA, &ib, &il, &ent, &n_ent, n_values != 0));
+            ORCD_TRY(orcd_rlev2_decode(c, ib, il, n_values, ent, n_ent, (int64_t *)d_idx, io));
+            const size_t cap = (size_t)longest * n_values;
+            ORCD_TRY(dev_alloc(c, cap, &p.bytes));
+            ORCD_TRY(orcd_string_dictionary_decode(c, (const int64_t *)p.tmp, (const uint8_t *)p.tmp2, dict_size,
+                                                   (const int64_t *)d_idx, n_values, (int64_t *)p.offsets,
+                                                   (uint8_t *)p.bytes, cap, ORCD_IN_DEVICE | ORCD_OUT_DEVICE));
+        } else {
+            return ORCD_UNSUPPORTED;  // RLE v1 encodings (README.md:23-25 of the crate: not implemented there either)
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->h_scalars, (int64_t *)p.offsets + n_values, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        num_bytes = c->h_scalars[0];
+        break;
+    }
+    default:
+        return ORCD_UNSUPPORTED;
+    }
+
+    if (row_aligned && n_values != rows) {
+        // dense -> one slot per row
+        void *aligned = nullptr;
+        if (p.values) {
+            ORCD_TRY(dev_alloc(c, rows * value_size, &aligned));
+            std::swap(aligned, p.values);  // p.values: the row-aligned array; aligned: the dense one
+            if (p.tmp) (void)hipFree(p.tmp);
+            p.tmp = aligned;                // released with the other temporaries
+            ORCD_TRY(scatter_device(c, (const uint8_t *)p.validity, rows, aligned, n_values, value_size,
+                                    p.values, false));
+        } else {
+            ORCD_TRY(dev_alloc(c, (rows + 1) * 8, &aligned));
+            std::swap(aligned, p.offsets);
+            if (p.tmp) (void)hipFree(p.tmp);
+            p.tmp = aligned;
+            ORCD_TRY(scatter_device(c, (const uint8_t *)p.validity, rows, aligned, n_values, 8, p.offsets, true));
+            HIP_TRY(c, hipMemcpyAsync((int64_t *)p.offsets + rows, (int64_t *)aligned + n_values, 8,
+                                      hipMemcpyDeviceToDevice, c->stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+
+    memset(out, 0, sizeof(*out));
+    out->type_kind = type_kind;
+    out->on_device = out_dev;
+    out->row_aligned = row_aligned;
+    out->num_rows = rows;
+    out->num_values = n_values;
+    out->num_slots = slots;
+    out->value_size = value_size;
+    out->num_bytes = num_bytes;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    void *r;
+    int rc = deliver(c, p.validity, rows, out_dev, &r);
+    p.validity = nullptr;
+    out->validity = (uint8_t *)r;
+    if (rc == ORCD_OK && p.values) {
+        rc = deliver(c, p.values, slots * value_size, out_dev, &r);
+        p.values = nullptr;
+        out->values = r;
+    }
+    if (rc == ORCD_OK && p.offsets) {
+        rc = deliver(c, p.offsets, (slots + 1) * 8, out_dev, &r);
+        p.offsets = nullptr;
+        out->offsets = (int64_t *)r;
+    }
+    if (rc == ORCD_OK && p.bytes) {
+        rc = deliver(c, p.bytes, num_bytes, out_dev, &r);
+        p.bytes = nullptr;
+        out->bytes = (uint8_t *)r;
+    }
+    if (rc != ORCD_OK) orcd_column_data_free(out);
+    return rc;
+}
+
+}  // namespace
+
+int orcd_decode_column(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
+                       uint32_t column, unsigned flags, orcd_column_data *out) {
+    if (!c || !file || !footer || !out) return ORCD_INVALID_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    if (orcd_file_compression(file) != 0) return ORCD_UNSUPPORTED;  // chunk framing is not decoded here
+    if (column >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
+    const int type_kind = orcd_file_type_kind(file, column);
+    orcd_column *col = nullptr;
+    ORCD_TRY(orcd_read_stripe_column(file, stripe, footer, column, &col));
+    DeviceGuard g(c->device);
+    const int rc = decode_column_impl(c, file, col, type_kind, flags, out);
+    (void)hipStreamSynchronize(c->stream);  // the column's bytes were read by asynchronous copies
+    orcd_column_free(col);
+    if (rc != ORCD_OK) memset(out, 0, sizeof(*out));
+    return rc;
+}
+
+void orcd_column_data_free(orcd_column_data *d) {
+    if (!d) return;
+    for (void *p : {(void *)d->validity, d->values, (void *)d->offsets, (void *)d->bytes}) {
+        if (!p) continue;
+        if (d->on_device) (void)hipFree(p);
+        else free(p);
+    }
+    memset(d, 0, sizeof(*d));
 }
 
 }  // extern "C"

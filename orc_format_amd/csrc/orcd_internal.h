@@ -161,4 +161,15 @@ hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
                                     const uint8_t *dict_bytes, const int64_t *indices, uint64_t n,
                                     const int64_t *offsets_out, uint8_t *bytes_out);
 
+// Null scatter: per-tile counts of valid rows, then (after an exclusive scan of the counts)
+// out[r] = dense[number of valid rows before r] for valid rows, zero for null rows -- or the same
+// dense entry for null rows too when `carry` (string offsets).
+size_t scatter_tiles(uint64_t num_rows);
+constexpr uint64_t SC_MAX_TILE_COUNT = 1024;  // rows per tile: no tile count exceeds it
+hipError_t launch_valid_count(hipStream_t st, const uint8_t *validity, uint64_t num_rows,
+                              uint64_t *tile_counts);
+hipError_t launch_scatter_valid(hipStream_t st, const uint8_t *validity, uint64_t num_rows,
+                                const uint64_t *tile_prefix, const void *dense, uint64_t dense_len,
+                                size_t elem_size, void *out, bool carry);
+
 }  // namespace orcd

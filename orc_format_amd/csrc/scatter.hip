@@ -1,0 +1,144 @@
+// Null scatter for gfx950: dense non-null values + validity -> one slot per row.
+//
+// The orc-format harness returns (validity, dense values) per column
+// (tests/it/deserialize.rs:48-82: `num_of_values` = number of set validity entries, the values are
+// not moved to their rows).  A columnar consumer wants row-aligned arrays, so this pass computes
+// rank(r) = number of valid rows before r and writes out[r] = dense[rank(r)] for valid rows.
+//
+// Two kernels around a scan of per-tile counts: a wavefront owns a tile of 1024 rows, handled in 4
+// steps of 256 rows with lane i holding rows 4i .. 4i+3 of the step (one dword of validity bytes).
+#include "orcd_internal.h"
+
+namespace orcd {
+
+constexpr uint32_t SC_TILE_ROWS = 1024;  // per wavefront
+constexpr uint32_t SC_WAVES = 4;
+
+// Validity bytes of rows r .. r+3 as 4 flags (bit 0 of each byte: non-zero byte); rows past
+// num_rows read as null.
+__device__ __forceinline__ uint32_t load_flags4(const uint8_t *__restrict__ validity, uint64_t r,
+                                                uint64_t num_rows, bool aligned) {
+    uint32_t d = 0;
+    if (aligned && r + 4 <= num_rows) {
+        d = *(const uint32_t *)(validity + r);
+    } else {
+        for (uint32_t k = 0; k < 4; k++)
+            if (r + k < num_rows) d |= (uint32_t)validity[r + k] << (8 * k);
+    }
+    // any non-zero byte -> 1
+    return ((d | ((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_u32(uint32_t v, int lane) {
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(v, d);
+        if (lane >= d) v += up;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(SC_WAVES * 64) void valid_count_kernel(
+    const uint8_t *__restrict__ validity, uint64_t num_rows, uint64_t *__restrict__ tile_counts) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t tile = (uint64_t)blockIdx.x * SC_WAVES + (threadIdx.x >> 6);
+    const uint64_t base = tile * SC_TILE_ROWS;
+    if (base >= num_rows) return;
+    const bool aligned = (((uintptr_t)validity) & 3) == 0;
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t step = 0; step < 4; step++)
+        c += __popc(load_flags4(validity, base + 256 * step + 4 * lane, num_rows, aligned));
+    c = wave_sum_u32(c);
+    if (lane == 0) tile_counts[tile] = c;
+}
+
+// CARRY: null rows receive dense[rank] too (for string offsets: an empty value where the next
+// non-null one starts; dense then has num_values + 1 entries); otherwise they receive zero.
+template <typename T, bool CARRY>
+__global__ __launch_bounds__(SC_WAVES * 64) void scatter_valid_kernel(
+    const uint8_t *__restrict__ validity, uint64_t num_rows, const uint64_t *__restrict__ tile_prefix,
+    const T *__restrict__ dense, uint64_t dense_len, T *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t tile = (uint64_t)blockIdx.x * SC_WAVES + (threadIdx.x >> 6);
+    const uint64_t base = tile * SC_TILE_ROWS;
+    if (base >= num_rows) return;
+    const bool aligned = (((uintptr_t)validity) & 3) == 0;
+    uint64_t rank0 = tile_prefix[tile];  // valid rows before the current step (wave-uniform)
+#pragma unroll
+    for (uint32_t step = 0; step < 4; step++) {
+        const uint64_t r = base + 256 * step + 4 * lane;
+        const uint32_t flags = load_flags4(validity, r, num_rows, aligned);
+        const uint32_t c = __popc(flags);
+        const uint32_t incl = wave_inclusive_u32(c, (int)lane);
+        uint64_t rank = rank0 + incl - c;
+        rank0 += __shfl(incl, 63);
+        T v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const bool valid = (flags >> (8 * k)) & 1u;
+            v[k] = T(0);
+            // (rank < dense_len always holds when the counts match what the caller declared)
+            if ((valid || CARRY) && rank < dense_len) v[k] = dense[rank];
+            rank += valid ? 1 : 0;
+        }
+        if (r + 4 <= num_rows && (((uintptr_t)(out + r)) & (sizeof(T) * 4 - 1) & 15) == 0) {
+            if (sizeof(T) == 8) {
+                *(ulonglong2 *)(out + r) = make_ulonglong2((uint64_t)v[0], (uint64_t)v[1]);
+                *(ulonglong2 *)(out + r + 2) = make_ulonglong2((uint64_t)v[2], (uint64_t)v[3]);
+            } else if (sizeof(T) == 4) {
+                *(uint4 *)(out + r) = make_uint4((uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]);
+            } else {
+                *(uint32_t *)(out + r) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) |
+                                         ((uint32_t)v[3] << 24);
+            }
+        } else {
+            for (uint32_t k = 0; k < 4; k++)
+                if (r + k < num_rows) out[r + k] = v[k];
+        }
+    }
+}
+
+size_t scatter_tiles(uint64_t num_rows) { return (size_t)((num_rows + SC_TILE_ROWS - 1) / SC_TILE_ROWS); }
+
+hipError_t launch_valid_count(hipStream_t st, const uint8_t *validity, uint64_t num_rows,
+                              uint64_t *tile_counts) {
+    const size_t tiles = scatter_tiles(num_rows);
+    if (tiles == 0) return hipSuccess;
+    valid_count_kernel<<<(uint32_t)((tiles + SC_WAVES - 1) / SC_WAVES), SC_WAVES * 64, 0, st>>>(
+        validity, num_rows, tile_counts);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_scatter_t(hipStream_t st, const uint8_t *validity, uint64_t num_rows,
+                                   const uint64_t *tile_prefix, const void *dense, uint64_t dense_len,
+                                   void *out, bool carry) {
+    const size_t tiles = scatter_tiles(num_rows);
+    const uint32_t blocks = (uint32_t)((tiles + SC_WAVES - 1) / SC_WAVES);
+    if (carry)
+        scatter_valid_kernel<T, true><<<blocks, SC_WAVES * 64, 0, st>>>(
+            validity, num_rows, tile_prefix, (const T *)dense, dense_len, (T *)out);
+    else
+        scatter_valid_kernel<T, false><<<blocks, SC_WAVES * 64, 0, st>>>(
+            validity, num_rows, tile_prefix, (const T *)dense, dense_len, (T *)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_valid(hipStream_t st, const uint8_t *validity, uint64_t num_rows,
+                                const uint64_t *tile_prefix, const void *dense, uint64_t dense_len,
+                                size_t elem_size, void *out, bool carry) {
+    if (num_rows == 0) return hipSuccess;
+    switch (elem_size) {
+    case 8: return launch_scatter_t<uint64_t>(st, validity, num_rows, tile_prefix, dense, dense_len, out, carry);
+    case 4: return launch_scatter_t<uint32_t>(st, validity, num_rows, tile_prefix, dense, dense_len, out, carry);
+    case 1: return launch_scatter_t<uint8_t>(st, validity, num_rows, tile_prefix, dense, dense_len, out, carry);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace orcd

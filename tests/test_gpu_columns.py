@@ -1,0 +1,140 @@
+"""orcd_decode_column (one call per column of a stripe) and orcd_scatter_valid (dense values ->
+one slot per row), against the Apache ORC C++ reader (pyarrow) on the golden files."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FILES = ["test.orc", "long_bool.orc", "string_long.orc", "string_dict.orc", "string_long_long.orc",
+         "mixed_compression.orc", "mixed_speed.orc"]
+INT_KINDS, STR_KINDS = (2, 3, 4, 15), (7, 8, 16, 17)
+
+
+def _hip():
+    """The HIP runtime this process already has loaded (torch's), for a raw device-to-device copy."""
+    import ctypes as C
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                return C.CDLL(line.split()[-1])
+    raise RuntimeError("libamdhip64 is not loaded")
+
+
+def _strings(offsets, data):
+    b = bytes(data)
+    return [b[offsets[i]:offsets[i + 1]].decode("utf-8") for i in range(len(offsets) - 1)]
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_decode_column_matches_pyarrow(golden_dir, name):
+    orc = pytest.importorskip("pyarrow.orc")
+    from orc_format_amd import default_context, read
+    ctx = default_context()
+    path = os.path.join(golden_dir, name)
+    f = orc.ORCFile(path)
+    md = read.read_metadata(path)
+    assert len(md.stripes) == f.nstripes
+    checked = 0
+    for stripe in range(f.nstripes):
+        table = f.read_stripe(stripe)
+        footer = read.read_stripe_footer(md, stripe)
+        for ci, cname in enumerate(table.schema.names):
+            want = table.column(cname).to_pylist()
+            kind = md.types[ci + 1]
+            dense = ctx.decode_column(md, stripe, footer, ci + 1)
+            rows = ctx.decode_column(md, stripe, footer, ci + 1, row_aligned=True)
+            valid = [w is not None for w in want]
+            assert dense["validity"].tolist() == valid and rows["validity"].tolist() == valid
+            assert dense["num_values"] == sum(valid)
+            nn = [w for w in want if w is not None]
+            if kind in INT_KINDS or kind == 0:
+                assert dense["values"].tolist() == [int(w) for w in nn]
+                assert rows["values"].tolist() == [int(w) if w is not None else 0 for w in want]
+            elif kind in (5, 6):
+                dt = np.float32 if kind == 5 else np.float64
+                assert dense["values"].tobytes() == np.array(nn, dtype=dt).tobytes()
+                assert rows["values"].tobytes() == np.array([w if w is not None else 0.0 for w in want], dtype=dt).tobytes()
+            elif kind in STR_KINDS:
+                assert _strings(dense["offsets"], dense["bytes"]) == nn
+                assert _strings(rows["offsets"], rows["bytes"]) == [w if w is not None else "" for w in want]
+            else:
+                continue
+            checked += 1
+    assert checked > 0
+
+
+def test_decode_column_on_device(golden_dir):
+    """ORCD_OUT_DEVICE: the arrays stay in device memory and are the same bytes."""
+    import ctypes as C
+    import torch
+    from orc_format_amd import _native as N
+    from orc_format_amd import default_context, read
+    from orc_format_amd.error import check
+    ctx = default_context()
+    md = read.read_metadata(os.path.join(golden_dir, "mixed_compression.orc"))
+    footer = read.read_stripe_footer(md, 0)
+    lib = N.lib()
+    for column in range(1, len(md.types)):
+        host = ctx.decode_column(md, 0, footer, column)
+        cd = N.ColumnData()
+        check(lib.orcd_decode_column(ctx.handle, md._h, 0, footer._h, column, N.OUT_DEVICE | N.CHECK_UTF8,
+                                     C.byref(cd)), ctx.handle)
+        assert cd.on_device == 1 and cd.num_values == host["num_values"]
+
+        def fetch(ptr, nbytes):
+            t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            if nbytes:
+                assert _hip().hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(nbytes), 3) == 0
+            return t.cpu().numpy()
+        assert (fetch(cd.validity, cd.num_rows).astype(bool) == host["validity"]).all()
+        if cd.values:
+            assert fetch(cd.values, cd.num_slots * cd.value_size).tobytes() == host["values"].tobytes()
+        if cd.offsets:
+            assert fetch(cd.offsets, (cd.num_slots + 1) * 8).tobytes() == host["offsets"].tobytes()
+            assert fetch(cd.bytes, cd.num_bytes).tobytes() == host["bytes"].tobytes()
+        lib.orcd_column_data_free(C.byref(cd))
+        assert not cd.validity
+
+
+def test_decode_column_errors(golden_dir):
+    from orc_format_amd import _native as N
+    from orc_format_amd import default_context, read
+    from orc_format_amd.error import OrcError
+    ctx = default_context()
+    md = read.read_metadata(os.path.join(golden_dir, "test.orc"))
+    footer = read.read_stripe_footer(md, 0)
+    with pytest.raises(OrcError) as ei:
+        ctx.decode_column(md, 0, footer, 1000)
+    assert ei.value.code == N.INVALID_COLUMN
+    with pytest.raises(OrcError) as ei:
+        ctx.decode_column(md, 0, footer, 0)      # the root struct
+    assert ei.value.code in (N.UNSUPPORTED, N.INVALID_COLUMN)
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.float32, np.uint8])
+def test_scatter_valid(dtype):
+    from orc_format_amd import _native as N
+    from orc_format_amd import default_context
+    from orc_format_amd.error import OrcError
+    ctx = default_context()
+    rng = np.random.default_rng(31)
+    for rows, p in ((1, 1.0), (5, 0.5), (1023, 0.9), (1024, 0.0), (4097, 0.1), (300_001, 0.7), (2_500_000, 0.97)):
+        validity = rng.random(rows) < p
+        n = int(validity.sum())
+        dense = rng.integers(1, 200, size=n).astype(dtype)
+        want = np.zeros(rows, dtype=dtype)
+        want[validity] = dense
+        got = ctx.scatter_valid(validity, dense)
+        assert got.tobytes() == want.tobytes(), (rows, p)
+        if dtype == np.int64:
+            # offsets: null rows repeat the start of the next value
+            off = np.concatenate([[0], np.cumsum(rng.integers(0, 9, size=n))]).astype(np.int64)
+            rank = np.concatenate([[0], np.cumsum(validity)])[:-1]
+            got = ctx.scatter_valid(validity, off, carry=True)
+            assert (got == off[rank]).all()
+        if n:
+            with pytest.raises(OrcError) as ei:
+                ctx.scatter_valid(validity, dense[:-1])
+            assert ei.value.code == N.INVALID_ARGUMENT
