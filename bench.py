@@ -30,6 +30,9 @@ WORKLOADS = {
                   "RLE v2 Delta, 10-bit deltas, runs of 512, monotonic int64, seed 43"),
     "delta_w16": ("delta_monotonic", {"width": 16}, True,
                   "RLE v2 Delta, 16-bit deltas, runs of 512, monotonic int64, seed 43"),
+    "mixed_short_runs": ("mixed_short_runs", {}, False,
+                         "RLE v2 mix of ShortRepeat (3..10 copies) and Direct width 4 runs of 1..64 "
+                         "values, unsigned, seed 44: every 512-value window holds about 25 runs"),
     # direct-encoded string column: LENGTH (unsigned RLE v2 Direct, width 6) + DATA
     "strings_w6": ("string_lengths_w6", {}, False,
                    "string column, lengths U[8,56] as RLE v2 Direct width 6 runs of 512 (seed 46), "
@@ -39,7 +42,7 @@ WORKLOADS = {
                     "boolean stream, byte-RLE mix of 128-byte literal groups (70%) and 130-byte runs "
                     "of 0xff (30%), seed 45; one byte per value + number of set bits"),
 }
-DEFAULT_ROWS = {"strings_w6": 250_000_000, "boolean_mix": 4_000_000_000}
+DEFAULT_ROWS = {"strings_w6": 250_000_000, "boolean_mix": 4_000_000_000, "mixed_short_runs": 500_000_000}
 
 
 def main():
@@ -84,12 +87,20 @@ def main():
         return bench_strings(args, rank, world, local_rank, dist, desc, torch, np)
     if args.workload == "boolean_mix":
         return bench_boolean(args, rank, world, local_rank, dist, desc, torch, np)
-    n_runs = max(1, args.rows // 512)
-    rows = n_runs * 512
     # every rank decodes a different stripe set (seed offset by rank)
-    seed = {"direct_w17": 42, "delta_monotonic": 43}[gen_name] + 1000 * rank
-    full_size = rows == 1_000_000_000 - 1_000_000_000 % 512
-    stream, entries, expect = getattr(synth, gen_name)(n_runs, seed=seed, device="cuda", **gen_kw)
+    seed = {"direct_w17": 42, "delta_monotonic": 43, "mixed_short_runs": 44}[gen_name] + 1000 * rank
+    if gen_name == "mixed_short_runs":
+        n_runs = max(1, args.rows // 20)     # a run holds 19.5 values on average
+        stream, entries, expect, entry_values = synth.mixed_short_runs(n_runs, seed=seed, device="cuda")
+        rows = int(expect.numel())
+        cuts = (entry_values.cpu().numpy(), entries.cpu().numpy())
+        full_size = args.rows == DEFAULT_ROWS["mixed_short_runs"]
+    else:
+        n_runs = max(1, args.rows // 512)
+        rows = n_runs * 512
+        full_size = rows == 1_000_000_000 - 1_000_000_000 % 512
+        stream, entries, expect = getattr(synth, gen_name)(n_runs, seed=seed, device="cuda", **gen_kw)
+        cuts = None
     out = torch.empty(rows, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     stream_bytes = stream.numel()
@@ -170,7 +181,7 @@ def main():
         result["end_to_end"] = end_to_end(args, ctx, stream, entries, expect, rows, signed, torch)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, stream, rows, stream_bytes, signed, expect, np)
+        result["cpu_baseline"] = cpu_baseline(args, stream, rows, stream_bytes, signed, expect, np, cuts)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
@@ -448,46 +459,59 @@ def end_to_end(args, ctx, stream, entries, expect, rows, signed, torch):
             "note": "pinned host buffers, H2D + decode + D2H serialized on one stream"}
 
 
-def cpu_baseline(args, stream, rows, stream_bytes, signed, expect, np):
+def cpu_baseline(args, stream, rows, stream_bytes, signed, expect, np, cuts=None):
     """The CPU oracle (a C restatement of the reference's value-at-a-time decoder, not the Rust
-    crate itself) timed on the host cores over a bounded prefix of the same stream."""
+    crate itself) timed on the host cores over a bounded prefix of the same stream.
+    `cuts` = (values before, bytes before) at run boundaries where the stream may be cut; None for
+    the columns whose runs all hold 512 values in the same number of bytes."""
     import oracle_ctypes
     oracle = oracle_ctypes.load()
-    bytes_per_value = stream_bytes / rows
-    # calibrate on 4M values, then size the sample for about --cpu-seconds of single-thread work
-    def run(n_vals):
-        n_vals = (n_vals // 512) * 512
-        nbytes = int(round(n_vals * bytes_per_value))
+    if cuts is None:
+        run_bytes = stream_bytes // (rows // 512)
+
+        def cut(n_vals):   # largest boundary with at most n_vals values before it
+            k = max(1, min(n_vals, rows) // 512)
+            return k * 512, k * run_bytes
+    else:
+        cut_vals, cut_bytes = cuts
+
+        def cut(n_vals):
+            i = max(1, int(np.searchsorted(cut_vals, n_vals, side="right")) - 1)
+            if i >= len(cut_vals):
+                return rows, stream_bytes
+            return int(cut_vals[i]), int(cut_bytes[i])
+
+    def run(n_target):   # calibrate, then size the sample for about --cpu-seconds of one thread
+        n_vals, nbytes = cut(n_target)
         host = stream[:nbytes].cpu().numpy()
         t0 = time.perf_counter()
         rc, vals, _ = oracle.rlev2(host, n_vals, signed)
         dt = time.perf_counter() - t0
         assert rc == 0
         assert (vals == expect[:n_vals].cpu().numpy()).all(), "oracle disagrees with the generator"
-        return n_vals, dt
-    n_cal, dt_cal = run(min(rows, 4 << 20))
-    n = int(min(rows, max(n_cal, n_cal * args.cpu_seconds / max(dt_cal, 1e-6))))
-    n, dt = run(n)
+        return n_vals, nbytes, dt
+    n_cal, _, dt_cal = run(min(rows, 4 << 20))
+    n, nbytes, dt = run(int(min(rows, max(n_cal, n_cal * args.cpu_seconds / max(dt_cal, 1e-6)))))
     out = {"value": round(n * 8 / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
            "sample": "first %d values (%.1f MB of stream) of the same column, single thread, "
-                     "%.1f s" % (n, n * bytes_per_value / 1e6, dt)}
-    # The same oracle, stripe-parallel: the prefix is cut into one stripe per thread at run
-    # boundaries (the synthetic runs all have the same size) and the threads decode side by side
-    # (ctypes releases the GIL during the C call).  Reported beside the single-thread figure, which
-    # is what the reference -- a single-threaded iterator -- does.
+                     "%.1f s" % (n, nbytes / 1e6, dt)}
+    # The same oracle, stripe-parallel: the sample is cut into one stripe per thread at run
+    # boundaries and the threads decode side by side (ctypes releases the GIL during the C call).
+    # Reported beside the single-thread figure, which is what the reference -- a single-threaded
+    # iterator -- does.
     import threading
     threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1), 64))
-    run_bytes = stream_bytes // (rows // 512)
-    per = max(512, (n // threads) // 512 * 512)
-    host = stream[:per * threads // 512 * run_bytes].cpu().numpy()
-    parts = [host[i * (per // 512) * run_bytes:(i + 1) * (per // 512) * run_bytes] for i in range(threads)]
-    ok = [False] * threads
-    want_last = [int(expect[(i + 1) * per - 1].item()) for i in range(threads)]
+    bounds = [(0, 0)] + [cut((i + 1) * n // threads) for i in range(threads)]
+    bounds = [b for i, b in enumerate(bounds) if i == 0 or b[0] > bounds[i - 1][0]]
+    host = stream[:bounds[-1][1]].cpu().numpy()
+    parts = [(host[b0[1]:b1[1]], b1[0] - b0[0]) for b0, b1 in zip(bounds[:-1], bounds[1:])]
+    want_last = [int(expect[b[0] - 1].item()) for b in bounds[1:]]
+    ok = [False] * len(parts)
 
     def work(i):
-        rc, vals, _ = oracle.rlev2(parts[i], per, signed)
+        rc, vals, _ = oracle.rlev2(parts[i][0], parts[i][1], signed)
         ok[i] = rc == 0 and int(vals[-1]) == want_last[i]
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(parts))]
     t0 = time.perf_counter()
     for th in ths:
         th.start()
@@ -495,9 +519,10 @@ def cpu_baseline(args, stream, rows, stream_bytes, signed, expect, np):
         th.join()
     dtp = time.perf_counter() - t0
     assert all(ok), "parallel oracle run disagrees with the generator"
-    out["stripe_parallel"] = {"value": round(per * threads * 8 / dtp / 1e9, 4), "unit": "GB/s",
-                              "cores": threads,
-                              "sample": "%d stripes of %d values, one thread each, %.1f s" % (threads, per, dtp)}
+    out["stripe_parallel"] = {"value": round(bounds[-1][0] * 8 / dtp / 1e9, 4), "unit": "GB/s",
+                              "cores": len(parts),
+                              "sample": "%d stripes of about %d values, one thread each, %.1f s"
+                                        % (len(parts), bounds[-1][0] // len(parts), dtp)}
     return out
 
 

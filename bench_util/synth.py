@@ -170,3 +170,48 @@ def unpack_bools(packed, num_bits):
         b1 = min(packed.numel(), b0 + step)
         out[b0 * 8:b1 * 8] = ((packed[b0:b1, None] >> sh) & 1).view(-1)
     return out[:num_bits]
+
+
+def mixed_short_runs(n_runs, seed=44, runs_per_entry=64, device="cuda", chunk=1 << 20):
+    """Low-cardinality unsigned column as a writer emits it for values U{0..15} that repeat in
+    bursts: a random mix of ShortRepeat runs (3..10 copies, one value byte) and Direct runs of
+    width 4 and 1..64 values.  Returns (stream uint8, entries int64, values int64, entry_values
+    int64 = number of values before each entry point)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    is_sr = torch.rand(n_runs, device=device, generator=g) < 0.5
+    count = torch.randint(3, 11, (n_runs,), device=device, generator=g)      # ShortRepeat copies
+    dlen = torch.randint(1, 65, (n_runs,), device=device, generator=g)       # Direct values
+    n_out = torch.where(is_sr, count, dlen)
+    n_in = torch.where(is_sr, 2, 2 + (dlen + 1) // 2)
+    in_off = torch.cumsum(n_in, 0) - n_in
+    out_off = torch.cumsum(n_out, 0) - n_out
+    total_in, total_out = int(n_in.sum()), int(n_out.sum())
+    stream = torch.zeros(total_in, dtype=torch.uint8, device=device)
+    values = torch.zeros(total_out, dtype=torch.int64, device=device)
+    # headers: ShortRepeat 00 | (bytes-1)<<3 | (count-3); Direct 01 | code(4 bits)=3 <<1 | len-1 (9 bits)
+    h0 = torch.where(is_sr, count - 3, 0x40 | (3 << 1) | ((dlen - 1) >> 8))
+    stream[in_off] = h0.to(torch.uint8)
+    sr_val = torch.randint(0, 16, (n_runs,), device=device, generator=g)
+    stream[in_off + 1] = torch.where(is_sr, sr_val, (dlen - 1) & 0xFF).to(torch.uint8)
+    j10 = torch.arange(10, device=device)
+    j64 = torch.arange(64, device=device)
+    j32 = torch.arange(32, device=device)
+    for r0 in range(0, n_runs, chunk):
+        r1 = min(n_runs, r0 + chunk)
+        sr = is_sr[r0:r1]
+        # ShortRepeat values
+        o, c, v = out_off[r0:r1][sr], count[r0:r1][sr], sr_val[r0:r1][sr]
+        m = j10[None, :] < c[:, None]
+        values[(o[:, None] + j10)[m]] = v[:, None].expand(-1, 10)[m]
+        # Direct values and payload bytes
+        o, ln, io = out_off[r0:r1][~sr], dlen[r0:r1][~sr], in_off[r0:r1][~sr]
+        nib = torch.randint(0, 16, (o.numel(), 64), device=device, generator=g)
+        m = j64[None, :] < ln[:, None]
+        nib = nib * m
+        values[(o[:, None] + j64)[m]] = nib[m]
+        packed = (nib[:, 0::2] << 4) | nib[:, 1::2]
+        mb = j32[None, :] < ((ln + 1) // 2)[:, None]
+        stream[(io[:, None] + 2 + j32)[mb]] = packed[mb].to(torch.uint8)
+    entries = in_off[::runs_per_entry].contiguous()
+    return stream, entries, values, out_off[::runs_per_entry].contiguous()

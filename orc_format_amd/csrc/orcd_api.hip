@@ -144,17 +144,10 @@ int count_and_scan(orcd_ctx *c, uint32_t n_seg, uint64_t num_values, CountFn cou
 
 uint32_t segments_for(size_t n_entries) { return n_entries ? (uint32_t)n_entries : 1u; }
 
-struct Rlev2Table {
-    const RunEntry *runs;
-    const uint32_t *group_first;
-    const RunEntry *group_run;
-    uint32_t n_groups;
-    uint64_t total_runs;
-};
-
 // Builds the run table of one RLE v2 stream that is already on the device.
 int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
-                const uint64_t *d_entries, size_t n_entries, int is_signed, Rlev2Table *t) {
+                const uint64_t *d_entries, size_t n_entries, int is_signed, Rlev2Table *t,
+                bool full_table = false) {
     if (n_entries > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
@@ -173,14 +166,18 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
     ORCD_TRY(ensure(c, SLOT_GROUP_RUNS, (size_t)n_slots * sizeof(RunEntry), &group_runs));
     HIP_TRY(c, launch_rlev2_emit(c->stream, d_stream, len, entries, n_seg, is_signed, sr.table,
                                  (RunEntry *)runs, (uint32_t *)groups, (RunEntry *)group_runs,
-                                 (uint32_t)n_slots));
+                                 (uint32_t)n_slots, full_table));
     mark(c, 2);
     const uint64_t covered = std::min<uint64_t>(num_values, sr.totals.total_vals);
+    t->stream = d_stream;
+    t->len = len;
     t->runs = (const RunEntry *)runs;
     t->group_first = (const uint32_t *)groups;
     t->group_run = (const RunEntry *)group_runs;
     t->n_groups = (uint32_t)((covered + WINDOW - 1) >> WINDOW_SHIFT);
-    t->total_runs = sr.totals.total_runs;
+    t->n_runs = (uint32_t)sr.totals.total_runs;
+    t->num_values = num_values;
+    t->is_signed = is_signed;
     return ORCD_OK;
 }
 
@@ -189,9 +186,7 @@ int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_va
                  const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out) {
     Rlev2Table t;
     ORCD_TRY(rlev2_table(c, d_stream, len, num_values, d_entries, n_entries, is_signed, &t));
-    HIP_TRY(c, launch_rlev2_values(c->stream, d_stream, len, t.runs, t.group_first, t.group_run,
-                                   t.n_groups, (uint32_t)t.total_runs, num_values, is_signed,
-                                   d_out));
+    HIP_TRY(c, launch_rlev2_values(c->stream, t, d_out));
     mark(c, 3);
     return ORCD_OK;
 }
@@ -399,9 +394,9 @@ int orcd_rlev2_runs(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_v
     ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t), in_dev, &d_entries));
     Rlev2Table t;
     ORCD_TRY(rlev2_table(c, (const uint8_t *)d_stream, len, num_values, (const uint64_t *)d_entries,
-                         n_entries, (flags & ORCD_SIGNED) ? 1 : 0, &t));
-    RunEntry *h = new RunEntry[t.total_runs + 1];
-    hipError_t e = hipMemcpyAsync(h, t.runs, (t.total_runs + 1) * sizeof(RunEntry),
+                         n_entries, (flags & ORCD_SIGNED) ? 1 : 0, &t, true));
+    RunEntry *h = new RunEntry[t.n_runs + 1];
+    hipError_t e = hipMemcpyAsync(h, t.runs, (t.n_runs + 1) * sizeof(RunEntry),
                                   hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
@@ -410,7 +405,7 @@ int orcd_rlev2_runs(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_v
         return ORCD_HIP_ERROR;
     }
     size_t count = 0;
-    for (uint64_t i = 0; i < t.total_runs && h[i].out_off < num_values; i++, count++) {
+    for (uint64_t i = 0; i < t.n_runs && h[i].out_off < num_values; i++, count++) {
         if (count < max_runs) {
             runs[count].payload_offset = desc_payload(h[i].desc);
             runs[count].out_offset = h[i].out_off;
@@ -564,9 +559,7 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
         ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(std::max<uint64_t>(num_values, t.n_groups)) * sizeof(uint64_t), &sums));
         ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
         HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
-        HIP_TRY(c, launch_rlev2_group_sums(c->stream, ls, length_len, t.runs, t.group_first, t.group_run,
-                                           t.n_groups, (uint32_t)t.total_runs, num_values, 0,
-                                           (uint64_t *)gsums, (uint32_t *)flag));
+        HIP_TRY(c, launch_rlev2_group_sums(c->stream, t, (uint64_t *)gsums, (uint32_t *)flag));
         HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)gsums, t.n_groups, (uint64_t *)sums,
                                              data_len, (uint32_t *)flag));
         HIP_TRY(c, hipMemcpyAsync(c->h_scalars, (uint64_t *)gsums + t.n_groups, sizeof(uint64_t),
@@ -578,8 +571,7 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
         if (bad & 4u) {
             // PatchedBase runs in the LENGTH stream: their patches are applied after the fact,
             // so the lengths are materialised and scanned in place
-            HIP_TRY(c, launch_rlev2_values(c->stream, ls, length_len, t.runs, t.group_first, t.group_run,
-                                           t.n_groups, (uint32_t)t.total_runs, num_values, 0, d_offsets));
+            HIP_TRY(c, launch_rlev2_values(c->stream, t, d_offsets));
             HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
             HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)d_offsets, num_values,
                                                  (uint64_t *)sums, data_len, (uint32_t *)flag));
@@ -593,9 +585,7 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
             if (bad || total > data_len) return ORCD_OUT_OF_SPEC;
         } else {
             if ((bad & 1u) || total > data_len) return ORCD_OUT_OF_SPEC;
-            HIP_TRY(c, launch_rlev2_offsets(c->stream, ls, length_len, t.runs, t.group_first, t.group_run,
-                                            t.n_groups, (uint32_t)t.total_runs, num_values, 0,
-                                            (const uint64_t *)gsums, d_offsets));
+            HIP_TRY(c, launch_rlev2_offsets(c->stream, t, (const uint64_t *)gsums, d_offsets));
             HIP_TRY(c, hipMemcpyAsync(d_offsets + num_values, (uint64_t *)gsums + t.n_groups,
                                       sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
         }

@@ -102,24 +102,27 @@ hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t le
 hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                              const uint64_t *entries, uint32_t n_seg, int is_signed,
                              const SegTable &t, RunEntry *runs, uint32_t *group_first,
-                             RunEntry *group_run, uint32_t n_group_slots);
-hipError_t launch_rlev2_values(hipStream_t st, const uint8_t *stream, uint64_t len,
-                               const RunEntry *runs, const uint32_t *group_first,
-                               const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
-                               uint64_t num_values, int is_signed, int64_t *out);
+                             RunEntry *group_run, uint32_t n_group_slots, bool full_table);
+// What the header scan leaves for the value kernels of one stream.
+struct Rlev2Table {
+    const uint8_t *stream;
+    uint64_t len;
+    const RunEntry *runs;          // [n_runs + 1], the last one a sentinel
+    const uint32_t *group_first;   // per window of 512 values: index of the first run starting in it
+    const RunEntry *group_run;     // ... and a copy of that run, flagged when it is the only one
+    uint32_t n_groups;             // windows that hold wanted values
+    uint32_t n_runs;
+    uint64_t num_values;
+    int is_signed;
+};
+hipError_t launch_rlev2_values(hipStream_t st, const Rlev2Table &t, int64_t *out);
 // The same expansion, reduced: group_sums[g] = saturating sum of the values of the runs that
 // start in the g-th window of 512 values (bit 2 of *flags is raised when a PatchedBase run was
 // met: its patches are not in the sums) ...
-hipError_t launch_rlev2_group_sums(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                   const RunEntry *runs, const uint32_t *group_first,
-                                   const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
-                                   uint64_t num_values, int is_signed, uint64_t *group_sums,
+hipError_t launch_rlev2_group_sums(hipStream_t st, const Rlev2Table &t, uint64_t *group_sums,
                                    uint32_t *flags);
 // ... and, given the exclusive prefix sums of those, offsets[i] = sum of the values before i.
-hipError_t launch_rlev2_offsets(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                const RunEntry *runs, const uint32_t *group_first,
-                                const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
-                                uint64_t num_values, int is_signed, const uint64_t *group_prefix,
+hipError_t launch_rlev2_offsets(hipStream_t st, const Rlev2Table &t, const uint64_t *group_prefix,
                                 int64_t *offsets);
 
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,

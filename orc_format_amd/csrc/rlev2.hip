@@ -173,32 +173,41 @@ __device__ __forceinline__ uint32_t parse_run(const Window16 &w, const uint8_t *
 // parsed -- so a plain walk pays one memory round trip per run.  Every round here loads the header
 // at `pos` together with three more at pos + k * (size of the previous run) and then parses as
 // many of the four as the chain confirms: in a long column most neighbouring runs have the same
-// size, and four headers then cost one round trip.  A wrong guess only costs the extra loads.
+// size, and four headers then cost one round trip.  A wrong guess costs the extra loads, so the
+// guessing is switched on by two consecutive runs of equal size and off by the first that differs.
 template <typename Consume>
 __device__ __forceinline__ uint32_t walk_headers(const uint8_t *s, uint64_t len, uint64_t &pos,
                                                  uint64_t end, uint32_t max_runs, int is_signed,
                                                  Consume &&consume) {
-    uint64_t stride = 0;
+    uint64_t stride = 0, prev_stride = ~0ull;
     uint32_t n = 0, status = SEG_OK;
     ParsedRun r;
     auto step = [&](const Window16 &w) -> bool {
         status = parse_run(w, s, len, pos, is_signed, r);
         if (status != SEG_OK) return false;
         consume(r);
+        prev_stride = stride;
         stride = r.run_end - pos;
         pos = r.run_end;
         n++;
         return true;
     };
     while (pos < end && n < max_runs) {
+        // guess only while the guesses come true: where runs differ in size (short mixed runs)
+        // the three extra loads per round would be the bulk of the scan's memory traffic
+        const bool guess = stride != 0 && stride == prev_stride;
         const uint64_t p1 = pos + stride, p2 = p1 + stride, p3 = p2 + stride;
-        const bool h1 = stride != 0 && p1 < end, h2 = h1 && p2 < end, h3 = h2 && p3 < end;
+        const bool h1 = guess && p1 < end, h2 = h1 && p2 < end, h3 = h2 && p3 < end;
         const Window16 w0 = load_window(s, len, pos);
-        const Window16 w1 = load_window(s, len, h1 ? p1 : pos);
+        if (!h1) {
+            if (!step(w0)) break;
+            continue;
+        }
+        const Window16 w1 = load_window(s, len, p1);
         const Window16 w2 = load_window(s, len, h2 ? p2 : pos);
         const Window16 w3 = load_window(s, len, h3 ? p3 : pos);
         if (!step(w0)) break;
-        if (!(h1 && pos == p1 && n < max_runs)) continue;
+        if (!(pos == p1 && n < max_runs)) continue;
         if (!step(w1)) break;
         if (!(h2 && pos == p2 && n < max_runs)) continue;
         if (!step(w2)) break;
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
     uint32_t n_seg, int is_signed, SegTable t, RunEntry *__restrict__ runs,
     uint32_t *__restrict__ group_first, RunEntry *__restrict__ group_run,
-    uint32_t n_group_slots) {
+    uint32_t n_group_slots, int full_table) {
     const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
     const bool valid = seg < n_seg;
     // the first entry is taken to be offset 0 whatever its value
@@ -255,16 +264,18 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
             e.out_off = out_off;
             e.base = r.base;
             e.aux = r.aux;
-            runs[run_idx] = e;
-            // first run that starts inside its 512-value window?
+            // first run that starts inside its 512-value window?  and the only one?
             const uint64_t win = out_off >> WINDOW_SHIFT;
             const bool first = (out_off == 0) || (((out_off - prev_len) >> WINDOW_SHIFT) != win);
+            const bool single = first && ((out_off + r.len) >> WINDOW_SHIFT) != win;
+            // The value kernels read a single-run window's run from group_run only: its slot in
+            // the run table stays unwritten unless the table itself is what the caller wants.
+            if (!single || full_table) runs[run_idx] = e;
             if (first && win < n_group_slots) {
                 group_first[win] = run_idx;
-                // the window's own copy, so that the value kernel needs no dependent table load;
-                // flagged when no other run starts in this window
+                // the window's own copy, so that the value kernel needs no dependent table load
                 RunEntry ge = e;
-                if (((out_off + r.len) >> WINDOW_SHIFT) != win) ge.desc |= DESC_SINGLE;
+                if (single) ge.desc |= DESC_SINGLE;
                 group_run[win] = ge;
             }
             out_off += r.len;
@@ -845,6 +856,7 @@ __device__ __forceinline__ void decode_run_batch(const W &wv, const RunEntry *ru
         }
         const uint64_t need_mask = __ballot(needs);
         const bool any_scan = __ballot(scans) != 0;
+        const bool any_aux = __ballot((uint32_t)lane < nb && (my_kind == KIND_DELTA || my_kind == KIND_PATCHED_BASE)) != 0;
         bool use_lds = false;
         uint64_t lds_origin = 0;
         if (need_mask) {
@@ -864,23 +876,40 @@ __device__ __forceinline__ void decode_run_batch(const W &wv, const RunEntry *ru
             const uint64_t e0 = wbase + 128u * j + 2u * lane;
             uint64_t c[2];
             bool head[2], act[2];
+            act[0] = e0 >= lo && e0 < hi;
+            act[1] = e0 + 1 >= lo && e0 + 1 < hi;
+            // position of the pair's first value in the batch; a value outside [lo, hi) takes the
+            // place of its neighbour (or of lo) so that every lane looks up a run that exists
+            const uint32_t rel0 = act[0] ? (uint32_t)(e0 - batch_beg)
+                                         : (act[1] ? (uint32_t)(e0 + 1 - batch_beg) : (uint32_t)(lo - batch_beg));
+            const uint32_t rel1 = act[1] ? (uint32_t)(e0 + 1 - batch_beg) : rel0;
+            // largest k with rel_out[k] <= rel0 (lanes >= nb hold 0xFFFFFFFF); runs are not empty,
+            // so the pair's second value lies in run k or in run k + 1
+            int k = 0;
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                const uint32_t v = __shfl(my_rel, k + sft);
+                if (v <= rel0) k += sft;
+            }
+            const int kn = (k + 1) & 63;
+            RunFields fk, fn;
+            fk.rel_out = __shfl(my_rel, k);
+            fn.rel_out = __shfl(my_rel, kn);
+            if (k == 63) fn.rel_out = 0xFFFFFFFFu;  // no run after the batch's 64th
+            fk.desc = shfl64(me.desc, k);
+            fn.desc = shfl64(me.desc, kn);
+            fk.base = shfl64(me.base, k);
+            fn.base = shfl64(me.base, kn);
+            fk.aux = 0;
+            fn.aux = 0;
+            if (any_aux) {  // wave-uniform: only Delta and PatchedBase runs carry a second field
+                fk.aux = shfl64(me.aux, k);
+                fn.aux = shfl64(me.aux, kn);
+            }
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                const uint64_t e = e0 + t;
-                act[t] = e >= lo && e < hi;
-                const uint32_t e_rel = act[t] ? (uint32_t)(e - batch_beg) : (uint32_t)(lo - batch_beg);
-                // largest k with rel_out[k] <= e_rel (lanes >= nb hold 0xFFFFFFFF)
-                int k = 0;
-#pragma unroll
-                for (int sft = 32; sft >= 1; sft >>= 1) {
-                    const uint32_t v = __shfl(my_rel, k + sft);
-                    if (v <= e_rel) k += sft;
-                }
-                RunFields f;
-                f.rel_out = __shfl(my_rel, k);
-                f.desc = shfl64(me.desc, k);
-                f.base = shfl64(me.base, k);
-                f.aux = shfl64(me.aux, k);
+                const uint32_t e_rel = t ? rel1 : rel0;
+                const RunFields f = (t && rel1 >= fn.rel_out) ? fn : fk;
                 const uint32_t kind = desc_kind(f.desc), w = desc_width(f.desc);
                 const uint32_t idx = e_rel - f.rel_out;
                 uint64_t val = f.base;
@@ -903,7 +932,8 @@ __device__ __forceinline__ void decode_run_batch(const W &wv, const RunEntry *ru
                 if (packed) {
                     uint64_t m;
                     if (use_lds) {
-                        const uint32_t bit = (uint32_t)((desc_payload(f.desc) - lds_origin) << 3) + fidx * w;
+                        const uint32_t bit =
+                            (((uint32_t)desc_payload(f.desc) - (uint32_t)lds_origin) << 3) + fidx * w;
                         m = lds_bits64(wv.lds, bit, w);
                     } else {
                         const uint64_t pay = desc_payload(f.desc);
@@ -996,7 +1026,9 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
     if (MODE == MODE_OFFSETS) wv.acc = group_sums[g];  // wave-uniform address
 
     // The window's own copy of its first run: when that run is the only one starting in the
-    // window (flagged by the header scan) nothing else has to be loaded.
+    // window (flagged by the header scan) nothing else has to be loaded.  (One kernel for both
+    // kinds of group: a split into two launches with separate register budgets measured no
+    // faster on single-run columns and slower on columns of short runs.)
     const RunEntry *e = group_run + g;  // wave-uniform address
     const uint64_t desc = readfirstlane64(e->desc);
     if (desc & DESC_SINGLE) {
@@ -1032,7 +1064,7 @@ hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t le
                               const SegTable &t) {
     const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
     rlev2_scan_kernel<false><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, n_seg, is_signed, t,
-                                                          nullptr, nullptr, nullptr, 0);
+                                                          nullptr, nullptr, nullptr, 0, 0);
     return hipGetLastError();
 }
 
@@ -1045,53 +1077,37 @@ hipError_t launch_block_totals_scan(hipStream_t st, const SegTable &t, uint32_t 
 hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                              const uint64_t *entries, uint32_t n_seg, int is_signed,
                              const SegTable &t, RunEntry *runs, uint32_t *group_first,
-                             RunEntry *group_run, uint32_t n_group_slots) {
+                             RunEntry *group_run, uint32_t n_group_slots, bool full_table) {
     const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
     rlev2_scan_kernel<true><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, n_seg, is_signed, t,
                                                          runs, group_first, group_run,
-                                                         n_group_slots);
+                                                         n_group_slots, full_table ? 1 : 0);
     return hipGetLastError();
 }
 
 template <int MODE>
-static hipError_t launch_values_mode(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                     const RunEntry *runs, const uint32_t *group_first,
-                                     const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
-                                     uint64_t num_values, int is_signed, int64_t *out,
+static hipError_t launch_values_mode(hipStream_t st, const Rlev2Table &t, int64_t *out,
                                      uint64_t *group_sums, uint32_t *flags) {
-    if (n_groups == 0) return hipSuccess;
-    const uint32_t blocks = (n_groups + VAL_WAVES - 1) / VAL_WAVES;
+    if (t.n_groups == 0) return hipSuccess;
+    const uint32_t blocks = (t.n_groups + VAL_WAVES - 1) / VAL_WAVES;
     rlev2_values_kernel<MODE><<<blocks, VAL_WAVES * 64, 0, st>>>(
-        stream, len, runs, group_first, group_run, n_groups, n_runs, num_values, is_signed, out,
-        group_sums, flags);
+        t.stream, t.len, t.runs, t.group_first, t.group_run, t.n_groups, t.n_runs, t.num_values,
+        t.is_signed, out, group_sums, flags);
     return hipGetLastError();
 }
 
-hipError_t launch_rlev2_values(hipStream_t st, const uint8_t *stream, uint64_t len,
-                               const RunEntry *runs, const uint32_t *group_first,
-                               const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
-                               uint64_t num_values, int is_signed, int64_t *out) {
-    return launch_values_mode<MODE_VALUES>(st, stream, len, runs, group_first, group_run, n_groups,
-                                           n_runs, num_values, is_signed, out, nullptr, nullptr);
+hipError_t launch_rlev2_values(hipStream_t st, const Rlev2Table &t, int64_t *out) {
+    return launch_values_mode<MODE_VALUES>(st, t, out, nullptr, nullptr);
 }
 
-hipError_t launch_rlev2_group_sums(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                   const RunEntry *runs, const uint32_t *group_first,
-                                   const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
-                                   uint64_t num_values, int is_signed, uint64_t *group_sums,
+hipError_t launch_rlev2_group_sums(hipStream_t st, const Rlev2Table &t, uint64_t *group_sums,
                                    uint32_t *flags) {
-    return launch_values_mode<MODE_SUMS>(st, stream, len, runs, group_first, group_run, n_groups,
-                                         n_runs, num_values, is_signed, nullptr, group_sums, flags);
+    return launch_values_mode<MODE_SUMS>(st, t, nullptr, group_sums, flags);
 }
 
-hipError_t launch_rlev2_offsets(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                const RunEntry *runs, const uint32_t *group_first,
-                                const RunEntry *group_run, uint32_t n_groups, uint32_t n_runs,
-                                uint64_t num_values, int is_signed, const uint64_t *group_prefix,
+hipError_t launch_rlev2_offsets(hipStream_t st, const Rlev2Table &t, const uint64_t *group_prefix,
                                 int64_t *offsets) {
-    return launch_values_mode<MODE_OFFSETS>(st, stream, len, runs, group_first, group_run, n_groups,
-                                            n_runs, num_values, is_signed, offsets,
-                                            const_cast<uint64_t *>(group_prefix), nullptr);
+    return launch_values_mode<MODE_OFFSETS>(st, t, offsets, const_cast<uint64_t *>(group_prefix), nullptr);
 }
 
 }  // namespace orcd

@@ -35,6 +35,29 @@ def test_rlev2_generators(oracle, name, kw, signed):
         assert torch.equal(out, values)
 
 
+def test_mixed_short_runs_generator(oracle):
+    import torch
+    from bench_util import synth
+    from orc_format_amd import default_context
+    ctx = default_context()
+    stream, entries, values, entry_values = synth.mixed_short_runs(5000, device="cuda", chunk=1500)
+    n = values.numel()
+    rc, ref, consumed = oracle.rlev2(stream.cpu().numpy(), n, False)
+    assert rc == 0 and consumed == stream.numel()
+    assert (ref == values.cpu().numpy()).all()
+    rc, runs = oracle.runs(stream.cpu().numpy(), n)
+    starts = {r[3] for r in runs}      # header offset of every run
+    assert set(entries.cpu().tolist()) <= starts
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    for ent in (entries, None):
+        for count in (n, n - 7, int(entry_values[3])):
+            out.fill_(-1)
+            ctx.rlev2_device(stream.data_ptr(), stream.numel(), count, False, out.data_ptr(),
+                             ent.data_ptr() if ent is not None else 0, ent.numel() if ent is not None else 0)
+            ctx.synchronize()
+            assert torch.equal(out[:count], values[:count]) and (out[count:] == -1).all()
+
+
 @pytest.mark.parametrize("run_fraction", [0.0, 0.3, 1.0])
 def test_byte_rle_generator(oracle, run_fraction):
     import torch
