@@ -161,8 +161,9 @@ hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets
                                      uint64_t dict_total, const int64_t *indices, uint64_t n,
                                      uint64_t *lengths_out, uint32_t *error_flag);
 hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
-                                    const uint8_t *dict_bytes, const int64_t *indices, uint64_t n,
-                                    const int64_t *offsets_out, uint8_t *bytes_out);
+                                    const uint8_t *dict_bytes, uint64_t dict_total,
+                                    const int64_t *indices, uint64_t n, const int64_t *offsets_out,
+                                    uint8_t *bytes_out);
 
 // Null scatter: per-tile counts of valid rows, then (after an exclusive scan of the counts)
 // out[r] = dense[number of valid rows before r] for valid rows, zero for null rows -- or the same

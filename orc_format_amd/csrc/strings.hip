@@ -387,20 +387,49 @@ __global__ __launch_bounds__(256) void dictionary_lengths_kernel(
     lengths_out[i] = l;
 }
 
-// one 16-lane group per value copies the entry's bytes
+// One lane per value copies the entry's bytes: single bytes up to the first 4-byte boundary of
+// the destination, then whole dwords -- each put together from the two aligned source dwords it
+// straddles -- then the last bytes.  (A byte-sized access costs the memory pipeline as much per
+// lane as a dword-sized one; neighbouring lanes write neighbouring values, so the stores of a
+// wavefront fall into one stretch of the output.)
 __global__ __launch_bounds__(256) void dictionary_gather_kernel(
     const int64_t *__restrict__ dict_offsets, const uint8_t *__restrict__ dict_bytes,
-    const int64_t *__restrict__ indices, uint64_t n, const int64_t *__restrict__ offsets_out,
-    uint8_t *__restrict__ bytes_out) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t i = t >> 4;
-    const uint32_t sub = (uint32_t)t & 15;
+    uint64_t dict_total, const int64_t *__restrict__ indices, uint64_t n,
+    const int64_t *__restrict__ offsets_out, uint8_t *__restrict__ bytes_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t idx = (uint64_t)indices[i];
-    const int64_t src = dict_offsets[idx];
-    const int64_t l = dict_offsets[idx + 1] - src;
-    const int64_t dst = offsets_out[i];
-    for (int64_t k = sub; k < l; k += 16) bytes_out[dst + k] = dict_bytes[src + k];
+    const uint64_t src0 = (uint64_t)dict_offsets[idx];
+    uint64_t len = (uint64_t)dict_offsets[idx + 1] - src0;
+    if (src0 > dict_total || len > dict_total - src0) return;  // checked before: never taken
+    const uint8_t *src = dict_bytes + src0;
+    uint8_t *dst = bytes_out + offsets_out[i];
+    while (len && ((uintptr_t)dst & 3)) {
+        *dst++ = *src++;
+        len--;
+    }
+    if (len >= 4) {
+        const uint32_t sh = (uint32_t)((uintptr_t)src & 3);
+        const uint32_t *sw = (const uint32_t *)(src - sh);
+        const uintptr_t last_word = ((uintptr_t)(dict_bytes + dict_total - 1)) & ~(uintptr_t)3;
+        uint32_t lo = *sw;
+        while (len >= 4) {
+            sw++;
+            // the next aligned source dword is needed (and is inside the dictionary) unless the
+            // source is itself aligned
+            const uint32_t hi = (sh && (uintptr_t)sw <= last_word) ? *sw : 0u;
+            const uint32_t v = sh ? __builtin_amdgcn_alignbyte(hi, lo, sh) : lo;
+            *(uint32_t *)dst = v;
+            lo = sh ? hi : ((uintptr_t)sw <= last_word && len >= 8 ? *sw : 0u);
+            dst += 4;
+            src += 4;
+            len -= 4;
+        }
+    }
+    while (len) {
+        *dst++ = *src++;
+        len--;
+    }
 }
 
 hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
@@ -413,12 +442,12 @@ hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets
 }
 
 hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
-                                    const uint8_t *dict_bytes, const int64_t *indices, uint64_t n,
-                                    const int64_t *offsets_out, uint8_t *bytes_out) {
+                                    const uint8_t *dict_bytes, uint64_t dict_total,
+                                    const int64_t *indices, uint64_t n, const int64_t *offsets_out,
+                                    uint8_t *bytes_out) {
     if (n == 0) return hipSuccess;
-    const uint64_t threads = n * 16;
-    dictionary_gather_kernel<<<(uint32_t)((threads + 255) / 256), 256, 0, st>>>(
-        dict_offsets, dict_bytes, indices, n, offsets_out, bytes_out);
+    dictionary_gather_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(
+        dict_offsets, dict_bytes, dict_total, indices, n, offsets_out, bytes_out);
     return hipGetLastError();
 }
 
