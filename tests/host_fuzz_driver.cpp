@@ -1,0 +1,105 @@
+// Standalone driver for the host reader (orcd_host.cpp) meant to be built with
+// -fsanitize=address,undefined: opens the given ORC files, then many damaged copies of each,
+// and touches everything the reader offers.  Exit status 0 = no sanitizer report.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "orcd.h"
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() {
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static unsigned long checksum = 0;
+
+static int walk(const std::vector<uint8_t> &image) {
+    orcd_file *f = nullptr;
+    int rc = orcd_file_open_memory(image.data(), image.size(), &f);
+    if (rc != ORCD_OK) return rc;
+    const size_t n_types = orcd_file_num_types(f);
+    for (size_t t = 0; t < n_types && t < 64; t++) checksum += orcd_file_type_kind(f, t);
+    for (size_t stripe = 0; stripe < orcd_file_num_stripes(f) && stripe < 8; stripe++) {
+        orcd_stripe_info si;
+        orcd_file_stripe(f, stripe, &si);
+        orcd_stripe_footer *ft = nullptr;
+        if (orcd_read_stripe_footer(f, stripe, &ft) != ORCD_OK) continue;
+        for (size_t i = 0; i < orcd_stripe_footer_num_streams(ft) && i < 256; i++) {
+            orcd_stream_info info;
+            orcd_stripe_footer_stream(ft, i, &info);
+            checksum += info.kind;
+        }
+        for (uint32_t column = 0; column < n_types + 2 && column < 26; column++) {
+            orcd_column *col = nullptr;
+            if (orcd_read_stripe_column(f, stripe, ft, column, &col) != ORCD_OK) continue;
+            int kind;
+            uint32_t dict;
+            orcd_column_encoding(col, &kind, &dict);
+            for (int k = 0; k < 8; k++) {
+                const uint8_t *bytes;
+                size_t len;
+                if (orcd_column_get_stream(col, k, &bytes, &len) == ORCD_OK && len)
+                    checksum += bytes[0] + bytes[len - 1];
+                const uint64_t *entries;
+                size_t n_entries;
+                if (orcd_column_entry_points(f, col, k, &entries, &n_entries) == ORCD_OK && n_entries)
+                    checksum += entries[0] + entries[n_entries - 1];
+            }
+            orcd_column_free(col);
+        }
+        orcd_stripe_footer_free(ft);
+    }
+    orcd_file_close(f);
+    return ORCD_OK;
+}
+
+int main(int argc, char **argv) {
+    int opened = 0, refused = 0;
+    for (int a = 1; a < argc; a++) {
+        FILE *fp = fopen(argv[a], "rb");
+        if (!fp) return 2;
+        std::vector<uint8_t> image;
+        uint8_t buf[65536];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, fp)) > 0) image.insert(image.end(), buf, buf + got);
+        fclose(fp);
+        if (walk(image) != ORCD_OK) return 3;  // the undamaged file must open
+        const size_t n = image.size();
+        for (int c = 0; c < 400; c++) {
+            std::vector<uint8_t> m = image;
+            switch (c % 5) {
+            case 0:
+                for (int k = 0; k < 1 + (int)(rnd() % 5); k++) m[rnd() % n] = (uint8_t)rnd();
+                break;
+            case 1:
+                for (int k = 0; k < 1 + (int)(rnd() % 5); k++) m[n - 1 - rnd() % (n < 600 ? n : 600)] = (uint8_t)rnd();
+                break;
+            case 2:
+                m.resize(rnd() % n);
+                break;
+            case 3: {
+                const size_t cut = rnd() % (n / 2 + 1), tail = 1 + rnd() % (n < 400 ? n : 400);
+                std::vector<uint8_t> t(m.begin(), m.begin() + cut);
+                t.insert(t.end(), image.end() - tail, image.end());
+                m.swap(t);
+                break;
+            }
+            default: {
+                size_t p = n - 1 - rnd() % (n < 500 ? n : 500);
+                for (size_t k = p; k < n && k < p + 11; k++) m[k] = 0xFF;
+            }
+            }
+            if (walk(m) == ORCD_OK) opened++;
+            else refused++;
+        }
+    }
+    printf("opened %d refused %d checksum %lu\n", opened, refused, checksum);
+    return 0;
+}
