@@ -108,6 +108,27 @@ int orcd_rlev2_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t n
                       const uint64_t *entry_points, size_t n_entries, int64_t *out,
                       unsigned flags);
 
+/* Several RLE v2 streams that lie in one buffer -- the DATA streams of the integer columns of a
+ * stripe, say -- decoded by one set of kernel launches instead of one set per stream (a call costs
+ * about 50 microseconds whatever its size, which is what small columns are bounded by).  No
+ * counterpart in the crate, whose iterators are per stream (src/read/decode/rle_v2.rs:480-758).
+ *
+ * Every slice is a whole stream: `length` bytes at `offset` of `buffer` that encode exactly
+ * `num_values` values; all slices share the signedness given by ORCD_SIGNED.  `entry_points`
+ * (always a HOST pointer, nullable) are offsets relative to the slice, as for orcd_rlev2_decode.
+ * The values of slice i are written to out + (sum of num_values of the slices before i).
+ * A slice that does not hold exactly its num_values values, or does not parse, yields
+ * ORCD_OUT_OF_SPEC with *bad_slice (nullable) set to a slice at or before the first bad one;
+ * decode the slices one by one to pin it down. */
+typedef struct {
+    uint64_t offset, length, num_values;
+    const uint64_t *entry_points;
+    size_t n_entries;
+} orcd_rlev2_slice;
+int orcd_rlev2_decode_batch(orcd_ctx *ctx, const uint8_t *buffer, size_t buffer_len,
+                            const orcd_rlev2_slice *slices, size_t n_slices, int64_t *out,
+                            size_t *bad_slice, unsigned flags);
+
 /* One decoded run header as SignedRleV2RunIter / UnsignedRleV2RunIter expose it
  * (src/read/decode/rle_v2.rs:432-439, 629-636: the Direct / Delta / ShortRepeat variants and
  * their len()). */

@@ -31,6 +31,11 @@ class StreamInfo(C.Structure):
                 ("offset", C.c_uint64)]
 
 
+class Rlev2Slice(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("length", C.c_uint64), ("num_values", C.c_uint64),
+                ("entry_points", C.c_void_p), ("n_entries", C.c_size_t)]
+
+
 class ColumnData(C.Structure):
     _fields_ = [("type_kind", C.c_int), ("on_device", C.c_int), ("row_aligned", C.c_int),
                 ("num_rows", C.c_uint64), ("num_values", C.c_uint64), ("num_slots", C.c_uint64),
@@ -50,6 +55,7 @@ SIGNATURES = {
     "orcd_ctx_phase_ms": (C.c_float, [P, C.c_int]),
     "orcd_ctx_last_hip_error": (C.c_char_p, [P]),
     "orcd_rlev2_decode": (C.c_int, [P, P, SZ, SZ, U64P, SZ, P, C.c_uint]),
+    "orcd_rlev2_decode_batch": (C.c_int, [P, P, SZ, C.POINTER(Rlev2Slice), SZ, P, C.POINTER(SZ), C.c_uint]),
     "orcd_rlev2_runs": (C.c_int, [P, P, SZ, SZ, U64P, SZ, C.POINTER(OrcdRun), SZ, C.POINTER(SZ),
                                   C.c_uint]),
     "orcd_byte_rle_decode": (C.c_int, [P, P, SZ, SZ, U64P, SZ, P, C.c_uint]),

@@ -186,6 +186,35 @@ class Context:
         finally:
             self._lib.orcd_column_data_free(C.byref(cd))
 
+    def rlev2_batch(self, buffer, slices, signed, out_ptr=0, device=False):
+        """orcd_rlev2_decode_batch.  `slices`: (offset, length, num_values, entry_points or None)
+        per stream inside `buffer` (host bytes / numpy, or with device=True a raw device address
+        and its length as a tuple).  Returns the concatenated values (host), or with device=True
+        writes them at device address out_ptr."""
+        arr = (N.Rlev2Slice * len(slices))()
+        keep = []
+        total = 0
+        for i, (off, ln, nv, ent) in enumerate(slices):
+            e, ne = _entries(ent)
+            keep.append(e)
+            arr[i] = N.Rlev2Slice(off, ln, nv, e.ctypes.data if ne else None, ne)
+            total += nv
+        bad = C.c_size_t(0)
+        if device:
+            ptr, blen = buffer
+            rc = self._lib.orcd_rlev2_decode_batch(self._h, ptr, blen, arr, len(slices), out_ptr or None,
+                                                   C.byref(bad), (N.SIGNED if signed else 0) | N.IN_DEVICE | N.OUT_DEVICE)
+            self.bad_slice = bad.value
+            check(rc, self._h)
+            return None
+        b = _host_u8(buffer)
+        out = np.empty(total, dtype=np.int64)
+        rc = self._lib.orcd_rlev2_decode_batch(self._h, b.ctypes.data, b.size, arr, len(slices),
+                                               out.ctypes.data, C.byref(bad), N.SIGNED if signed else 0)
+        self.bad_slice = bad.value
+        check(rc, self._h)
+        return out
+
     # ---- device-pointer calls (raw addresses) -------------------------------------------------
     def rlev2_device(self, stream_ptr, length, num_values, signed, out_ptr, entries_ptr=0,
                      n_entries=0):

@@ -144,18 +144,23 @@ int count_and_scan(orcd_ctx *c, uint32_t n_seg, uint64_t num_values, CountFn cou
 
 uint32_t segments_for(size_t n_entries) { return n_entries ? (uint32_t)n_entries : 1u; }
 
-// Builds the run table of one RLE v2 stream that is already on the device.
+// Builds the run table of one RLE v2 stream that is already on the device.  d_seg_ends (nullable):
+// the end of every segment, for slices of a larger buffer decoded as one stream; seg_table
+// (nullable) receives the segment prefix sums for the caller's own checks.
 int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
                 const uint64_t *d_entries, size_t n_entries, int is_signed, Rlev2Table *t,
-                bool full_table = false) {
+                bool full_table = false, const uint64_t *d_seg_ends = nullptr,
+                SegTable *seg_table = nullptr) {
     if (n_entries > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
+    const uint64_t *seg_ends = n_entries ? d_seg_ends : nullptr;
     ScanResult sr;
-    ORCD_TRY(count_and_scan(c, n_seg, num_values, [&](const SegTable &t) {
-        return launch_rlev2_count(c->stream, d_stream, len, entries, n_seg, is_signed, t);
+    ORCD_TRY(count_and_scan(c, n_seg, num_values, [&](const SegTable &st) {
+        return launch_rlev2_count(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, st);
     }, &sr));
     mark(c, 1);
+    if (seg_table) *seg_table = sr.table;
     if (sr.totals.error) return (int)sr.totals.error;
     if (sr.totals.total_runs >= 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
     const uint64_t n_slots = ((sr.totals.total_vals + WINDOW - 1) >> WINDOW_SHIFT) + 1;
@@ -164,7 +169,7 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
     ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(RunEntry), &runs));
     ORCD_TRY(ensure(c, SLOT_GROUPS, (size_t)n_slots * sizeof(uint32_t), &groups));
     ORCD_TRY(ensure(c, SLOT_GROUP_RUNS, (size_t)n_slots * sizeof(RunEntry), &group_runs));
-    HIP_TRY(c, launch_rlev2_emit(c->stream, d_stream, len, entries, n_seg, is_signed, sr.table,
+    HIP_TRY(c, launch_rlev2_emit(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, sr.table,
                                  (RunEntry *)runs, (uint32_t *)groups, (RunEntry *)group_runs,
                                  (uint32_t)n_slots, full_table));
     mark(c, 2);
@@ -375,6 +380,91 @@ int orcd_rlev2_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num
     ORCD_TRY(rlev2_device(c, (const uint8_t *)d_stream, len, num_values, (const uint64_t *)d_entries,
                           n_entries, (flags & ORCD_SIGNED) ? 1 : 0, d_out));
     if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, num_values * sizeof(int64_t)));
+    return ORCD_OK;
+}
+
+int orcd_rlev2_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_len,
+                            const orcd_rlev2_slice *slices, size_t n_slices, int64_t *out,
+                            size_t *bad_slice, unsigned flags) {
+    if (bad_slice) *bad_slice = (size_t)-1;
+    if (!c || (buffer_len && !buffer) || (n_slices && !slices)) return ORCD_INVALID_ARGUMENT;
+    // One segment list over all slices: a slice starts a segment, and so does each of its entry
+    // points; every segment ends where the next one of its slice starts, or with the slice.
+    std::vector<uint64_t> starts, ends;
+    std::vector<uint32_t> first_seg;
+    std::vector<uint64_t> want_off;
+    std::vector<size_t> slice_of;
+    uint64_t total_values = 0;
+    for (size_t i = 0; i < n_slices; i++) {
+        const orcd_rlev2_slice &sl = slices[i];
+        if (sl.offset > buffer_len || sl.length > buffer_len - sl.offset || (sl.n_entries && !sl.entry_points))
+            return ORCD_INVALID_ARGUMENT;
+        if (sl.num_values == 0) continue;
+        first_seg.push_back((uint32_t)starts.size());
+        want_off.push_back(total_values);
+        slice_of.push_back(i);
+        starts.push_back(sl.offset);
+        uint64_t prev = 0;
+        for (size_t j = 1; j < sl.n_entries; j++) {  // the first entry is the start of the slice
+            const uint64_t e = sl.entry_points[j];
+            if (e <= prev || e >= sl.length) {  // not ascending inside the slice
+                if (bad_slice) *bad_slice = i;
+                return ORCD_OUT_OF_SPEC;
+            }
+            ends.push_back(sl.offset + e);
+            starts.push_back(sl.offset + e);
+            prev = e;
+        }
+        ends.push_back(sl.offset + sl.length);
+        total_values += sl.num_values;
+    }
+    if (total_values == 0) return ORCD_OK;
+    if (!out || starts.size() > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    mark(c, 0);
+    const void *d_buffer, *d_starts, *d_ends, *d_first;
+    ORCD_TRY(stage_in(c, SLOT_IN_A, buffer, buffer_len, in_dev, &d_buffer));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, starts.data(), starts.size() * sizeof(uint64_t), false, &d_starts));
+    ORCD_TRY(stage_in(c, SLOT_IN_C, ends.data(), ends.size() * sizeof(uint64_t), false, &d_ends));
+    ORCD_TRY(stage_in(c, SLOT_IN_D, first_seg.data(), first_seg.size() * sizeof(uint32_t), false, &d_first));
+    int64_t *d_out = out;
+    if (!out_dev) {
+        void *p;
+        ORCD_TRY(ensure(c, SLOT_OUT_A, total_values * sizeof(int64_t), &p));
+        d_out = (int64_t *)p;
+    }
+    Rlev2Table t;
+    SegTable seg = {};
+    const int rc = rlev2_table(c, (const uint8_t *)d_buffer, buffer_len, total_values, (const uint64_t *)d_starts,
+                               starts.size(), (flags & ORCD_SIGNED) ? 1 : 0, &t, false,
+                               (const uint64_t *)d_ends, &seg);
+    if (!seg.seg_local) return rc;  // failed before the scan: there is nothing to look at
+    // Decoded as one stream, the values of a slice land where they belong only if every slice
+    // before it holds exactly the values it was said to hold: compare the scan's value offsets at
+    // the slice starts with the prefix sums of num_values.
+    void *d_val_off;
+    ORCD_TRY(ensure(c, SLOT_TMP, first_seg.size() * sizeof(uint64_t), &d_val_off));
+    std::vector<uint64_t> got_off(first_seg.size());
+    HIP_TRY(c, launch_seg_value_offsets(c->stream, seg, (const uint32_t *)d_first, (uint32_t)first_seg.size(),
+                                        (uint64_t *)d_val_off));
+    HIP_TRY(c, hipMemcpyAsync(got_off.data(), d_val_off, got_off.size() * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < got_off.size(); k++) {
+        if (got_off[k] != want_off[k]) {  // slice k - 1 is the first that is off
+            if (bad_slice) *bad_slice = slice_of[k ? k - 1 : 0];
+            return ORCD_OUT_OF_SPEC;
+        }
+    }
+    if (rc != ORCD_OK) {  // a run that does not parse, or too few values: in or after the last good start
+        if (bad_slice) *bad_slice = slice_of.back();
+        return rc;
+    }
+    HIP_TRY(c, launch_rlev2_values(c->stream, t, d_out));
+    mark(c, 3);
+    if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, total_values * sizeof(int64_t)));
     return ORCD_OK;
 }
 

@@ -96,13 +96,17 @@ struct ByteRun {
 // ---- launchers (defined in the .hip files, called from the C ABI layer) ---------------------
 struct SegTable;  // seg_scan.h
 
+// entries: start offset of every segment; seg_ends (nullable): its end, when the segments are
+// slices of a larger buffer rather than one gapless stream.
 hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t len,
-                              const uint64_t *entries, uint32_t n_seg, int is_signed,
-                              const SegTable &t);
+                              const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
+                              int is_signed, const SegTable &t);
 hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
-                             const uint64_t *entries, uint32_t n_seg, int is_signed,
-                             const SegTable &t, RunEntry *runs, uint32_t *group_first,
+                             const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
+                             int is_signed, const SegTable &t, RunEntry *runs, uint32_t *group_first,
                              RunEntry *group_run, uint32_t n_group_slots, bool full_table);
+hipError_t launch_seg_value_offsets(hipStream_t st, const SegTable &t, const uint32_t *first_seg,
+                                    uint32_t n, uint64_t *out);
 // What the header scan leaves for the value kernels of one stream.
 struct Rlev2Table {
     const uint8_t *stream;

@@ -226,14 +226,20 @@ __device__ __forceinline__ uint32_t walk_headers(const uint8_t *s, uint64_t len,
 template <bool EMIT>
 __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
-    uint32_t n_seg, int is_signed, SegTable t, RunEntry *__restrict__ runs,
-    uint32_t *__restrict__ group_first, RunEntry *__restrict__ group_run,
-    uint32_t n_group_slots, int full_table) {
+    const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
+    RunEntry *__restrict__ runs, uint32_t *__restrict__ group_first,
+    RunEntry *__restrict__ group_run, uint32_t n_group_slots, int full_table) {
     const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
     const bool valid = seg < n_seg;
-    // the first entry is taken to be offset 0 whatever its value
-    uint64_t pos = (valid && entries && seg > 0) ? entries[seg] : 0;
-    const uint64_t end = (valid && entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
+    // A segment runs from its entry to the next entry -- or, when seg_ends is given (slices of a
+    // larger buffer decoded as one stream, with gaps between them), to its own end.  Without
+    // seg_ends the first entry is taken to be offset 0 whatever its value.
+    uint64_t pos = (valid && entries && (seg > 0 || seg_ends)) ? entries[seg] : 0;
+    uint64_t end = (valid && entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
+    if (valid && seg_ends) end = seg_ends[seg];
+    // a slice is a stream of its own: a run that reaches past its end is cut short, whatever
+    // bytes follow it in the buffer
+    const uint64_t limit = seg_ends ? (end < len ? end : len) : len;
     const bool last_seg = seg + 1 == n_seg;
     if (pos > len) pos = len;
 
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
         uint64_t n_vals = 0;
         if (end > len || end < pos) status = SEG_MISALIGNED;
         if (valid && status == SEG_OK) {
-            status = walk_headers(s, len, pos, end, 0xFFFFFFFFu, is_signed, [&](const ParsedRun &r) {
+            status = walk_headers(s, limit, pos, end, 0xFFFFFFFFu, is_signed, [&](const ParsedRun &r) {
                 n_runs++;
                 n_vals += r.len;
                 last_len = r.len;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
         uint32_t run_idx = so.run_off;
         uint32_t prev_len = so.prev_len;  // 0 only before the very first run
         // the counting pass found n_runs well-formed runs from here
-        walk_headers(s, len, pos, end, n_runs, is_signed, [&](const ParsedRun &r) {
+        walk_headers(s, limit, pos, end, n_runs, is_signed, [&](const ParsedRun &r) {
             RunEntry e;
             e.desc = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg);
             e.out_off = out_off;
@@ -1060,11 +1066,11 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
 // ---------------------------------------------------------------------------------------------
 
 hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t len,
-                              const uint64_t *entries, uint32_t n_seg, int is_signed,
-                              const SegTable &t) {
+                              const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
+                              int is_signed, const SegTable &t) {
     const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
-    rlev2_scan_kernel<false><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, n_seg, is_signed, t,
-                                                          nullptr, nullptr, nullptr, 0, 0);
+    rlev2_scan_kernel<false><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, seg_ends, n_seg,
+                                                          is_signed, t, nullptr, nullptr, nullptr, 0, 0);
     return hipGetLastError();
 }
 
@@ -1075,13 +1081,27 @@ hipError_t launch_block_totals_scan(hipStream_t st, const SegTable &t, uint32_t 
 }
 
 hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
-                             const uint64_t *entries, uint32_t n_seg, int is_signed,
-                             const SegTable &t, RunEntry *runs, uint32_t *group_first,
+                             const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
+                             int is_signed, const SegTable &t, RunEntry *runs, uint32_t *group_first,
                              RunEntry *group_run, uint32_t n_group_slots, bool full_table) {
     const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
-    rlev2_scan_kernel<true><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, n_seg, is_signed, t,
-                                                         runs, group_first, group_run,
+    rlev2_scan_kernel<true><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, seg_ends, n_seg,
+                                                         is_signed, t, runs, group_first, group_run,
                                                          n_group_slots, full_table ? 1 : 0);
+    return hipGetLastError();
+}
+
+// out[i] = number of values before segment first_seg[i] (after the scan of the counts)
+__global__ void seg_value_offsets_kernel(SegTable t, const uint32_t *__restrict__ first_seg, uint32_t n,
+                                         uint64_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = seg_global_offset(t, first_seg[i]).val_off;
+}
+
+hipError_t launch_seg_value_offsets(hipStream_t st, const SegTable &t, const uint32_t *first_seg,
+                                    uint32_t n, uint64_t *out) {
+    if (n == 0) return hipSuccess;
+    seg_value_offsets_kernel<<<(n + 255) / 256, 256, 0, st>>>(t, first_seg, n, out);
     return hipGetLastError();
 }
 
