@@ -300,6 +300,13 @@ int orcd_decode_column(orcd_ctx *ctx, orcd_file *file, size_t stripe,
                        orcd_column_data *out);
 void orcd_column_data_free(orcd_column_data *data);
 
+/* The same for several columns of one stripe: out[i] receives column columns[i].  The DATA streams
+ * of the integer columns are decoded together (orcd_rlev2_decode_batch), the other streams column
+ * by column.  On failure nothing is left in `out`. */
+int orcd_decode_stripe(orcd_ctx *ctx, orcd_file *file, size_t stripe,
+                       const orcd_stripe_footer *footer, const uint32_t *columns, size_t n_columns,
+                       unsigned flags, orcd_column_data *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,7 @@ SIGNATURES = {
     "orcd_scatter_valid": (C.c_int, [P, P, SZ, P, SZ, SZ, P, C.c_uint]),
     "orcd_decode_column": (C.c_int, [P, P, SZ, P, C.c_uint32, C.c_uint, C.POINTER(ColumnData)]),
     "orcd_column_data_free": (None, [C.POINTER(ColumnData)]),
+    "orcd_decode_stripe": (C.c_int, [P, P, SZ, P, C.POINTER(C.c_uint32), SZ, C.c_uint, C.POINTER(ColumnData)]),
 }
 
 _lib = None

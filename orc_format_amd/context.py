@@ -24,6 +24,25 @@ def _entries(entry_points):
     return e, e.size
 
 
+def _column_dict(cd):
+    """Host arrays of an orcd_column_data as numpy copies."""
+    def arr(ptr, count, dtype):
+        if count == 0:
+            return np.empty(0, dtype=dtype)
+        buf = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype).copy()
+    out = {"type_kind": cd.type_kind, "num_values": cd.num_values,
+           "validity": arr(cd.validity, cd.num_rows, np.uint8).astype(bool)}
+    if cd.values:
+        dtype = {(5, 4): np.float32, (6, 8): np.float64}.get(
+            (cd.type_kind, cd.value_size), {8: np.int64, 1: np.uint8}.get(cd.value_size))
+        out["values"] = arr(cd.values, cd.num_slots, dtype)
+    if cd.offsets:
+        out["offsets"] = arr(cd.offsets, cd.num_slots + 1, np.int64)
+        out["bytes"] = arr(cd.bytes, cd.num_bytes, np.uint8) if cd.bytes else np.empty(0, np.uint8)
+    return out
+
+
 class Context:
     def __init__(self, device=0):
         self._lib = N.lib()
@@ -168,23 +187,23 @@ class Context:
         check(self._lib.orcd_decode_column(self._h, metadata._h, stripe, footer._h, column, flags,
                                            C.byref(cd)), self._h)
         try:
-            def arr(ptr, count, dtype):
-                if count == 0:
-                    return np.empty(0, dtype=dtype)
-                buf = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
-                return np.frombuffer(buf, dtype=dtype).copy()
-            out = {"type_kind": cd.type_kind, "num_values": cd.num_values,
-                   "validity": arr(cd.validity, cd.num_rows, np.uint8).astype(bool)}
-            if cd.values:
-                dtype = {(5, 4): np.float32, (6, 8): np.float64}.get(
-                    (cd.type_kind, cd.value_size), {8: np.int64, 1: np.uint8}.get(cd.value_size))
-                out["values"] = arr(cd.values, cd.num_slots, dtype)
-            if cd.offsets:
-                out["offsets"] = arr(cd.offsets, cd.num_slots + 1, np.int64)
-                out["bytes"] = arr(cd.bytes, cd.num_bytes, np.uint8) if cd.bytes else np.empty(0, np.uint8)
-            return out
+            return _column_dict(cd)
         finally:
             self._lib.orcd_column_data_free(C.byref(cd))
+
+    def decode_stripe(self, metadata, stripe, footer, columns, check_utf8=True, row_aligned=False):
+        """Several columns of one stripe through orcd_decode_stripe (host results): a list of the
+        dicts decode_column returns."""
+        cols = (C.c_uint32 * len(columns))(*columns)
+        cds = (N.ColumnData * len(columns))()
+        flags = (N.CHECK_UTF8 if check_utf8 else 0) | (N.ROW_ALIGNED if row_aligned else 0)
+        check(self._lib.orcd_decode_stripe(self._h, metadata._h, stripe, footer._h, cols, len(columns),
+                                           flags, cds), self._h)
+        try:
+            return [_column_dict(cd) for cd in cds]
+        finally:
+            for cd in cds:
+                self._lib.orcd_column_data_free(C.byref(cd))
 
     def rlev2_batch(self, buffer, slices, signed, out_ptr=0, device=False):
         """orcd_rlev2_decode_batch.  `slices`: (offset, length, num_values, entry_points or None)

@@ -60,4 +60,25 @@ extern "C" {
                                      length_entry_points: *const u64, n_length_entries: usize,
                                      data: *const u8, data_len: usize, num_values: usize,
                                      offsets: *mut i64, bytes_out: *mut u8, flags: c_uint) -> c_int;
+    pub fn orcd_string_dictionary_decode(ctx: *mut orcd_ctx, dict_offsets: *const i64,
+                                         dict_bytes: *const u8, dict_size: usize,
+                                         indices: *const i64, num_values: usize,
+                                         offsets_out: *mut i64, bytes_out: *mut u8,
+                                         bytes_capacity: usize, flags: c_uint) -> c_int;
+    pub fn orcd_rlev2_decode_batch(ctx: *mut orcd_ctx, buffer: *const u8, buffer_len: usize,
+                                   slices: *const orcd_rlev2_slice, n_slices: usize, out: *mut i64,
+                                   bad_slice: *mut usize, flags: c_uint) -> c_int;
+    pub fn orcd_scatter_valid(ctx: *mut orcd_ctx, validity: *const u8, num_rows: usize,
+                              dense: *const c_void, num_values: usize, elem_size: usize,
+                              out: *mut c_void, flags: c_uint) -> c_int;
+}
+
+/// One stream inside the buffer handed to `orcd_rlev2_decode_batch` (include/orcd.h).
+#[repr(C)]
+pub struct orcd_rlev2_slice {
+    pub offset: u64,
+    pub length: u64,
+    pub num_values: u64,
+    pub entry_points: *const u64,
+    pub n_entries: usize,
 }

@@ -65,6 +65,36 @@ def test_decode_column_matches_pyarrow(golden_dir, name):
     assert checked > 0
 
 
+@pytest.mark.parametrize("name", ["test.orc", "mixed_compression.orc", "mixed_speed.orc", "string_dict.orc"])
+def test_decode_stripe_equals_decode_column(golden_dir, name):
+    """All columns of a stripe in one call (integer DATA streams batched) give what the
+    per-column calls give."""
+    from orc_format_amd import default_context, read
+    ctx = default_context()
+    md = read.read_metadata(os.path.join(golden_dir, name))
+    for stripe in range(min(len(md.stripes), 3)):
+        footer = read.read_stripe_footer(md, stripe)
+        columns = list(range(1, len(md.types)))
+        for row_aligned in (False, True):
+            got = ctx.decode_stripe(md, stripe, footer, columns, row_aligned=row_aligned)
+            assert len(got) == len(columns)
+            for column, g in zip(columns, got):
+                want = ctx.decode_column(md, stripe, footer, column, row_aligned=row_aligned)
+                assert g.keys() == want.keys()
+                for key in want:
+                    if isinstance(want[key], np.ndarray):
+                        assert g[key].tobytes() == want[key].tobytes(), (column, key)
+                    else:
+                        assert g[key] == want[key], (column, key)
+    # a subset, in another order, and nothing at all
+    footer = read.read_stripe_footer(md, 0)
+    some = list(range(len(md.types) - 1, 0, -2))
+    got = ctx.decode_stripe(md, 0, footer, some)
+    for column, g in zip(some, got):
+        assert g["validity"].tolist() == ctx.decode_column(md, 0, footer, column)["validity"].tolist()
+    assert ctx.decode_stripe(md, 0, footer, []) == []
+
+
 def test_decode_column_on_device(golden_dir):
     """ORCD_OUT_DEVICE: the arrays stay in device memory and are the same bytes."""
     import ctypes as C
