@@ -12,6 +12,7 @@
 
 namespace orcd {
 
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 constexpr uint64_t BR_IS_RUN = 1ull << 48;
 constexpr uint32_t BR_WINDOW_SHIFT = 7;  // the expansion looks runs up per window of 128 bytes
 constexpr uint32_t BR_WINDOW = 1u << BR_WINDOW_SHIFT;
@@ -185,39 +186,45 @@ __device__ __forceinline__ uint32_t stream_byte(const uint8_t *s, uint64_t src, 
 }
 
 // Booleans: every decoded byte is 8 values, most significant bit first (boolean_rle.rs:98,118).
-// A wavefront takes a tile of 512 decoded bytes in 4 steps; in a step lane i owns bytes
+// A wavefront takes a tile of BOOL_TILE decoded bytes in BOOL_STEPS steps (a tile costs three
+// dependent memory round trips -- window index, runs, stream bytes -- whatever its size, and
+// with small tiles those round trips, not the bytes, bound the kernel); in a step lane i owns bytes
 // 128*step + 2*i and the next one, i.e. 16 values, so that each store instruction writes 1 KiB of
 // consecutive values.  The runs that overlap the tile are loaded once, one per lane, and every
 // lane then finds the runs of its bytes with register shuffles (a tile overlapped by more than 64
 // runs falls back to per-lane walks of the run table).  out_bytes: one byte per value;
 // out_bitmap: the same bits least-significant-first; *set_bits: the number of ones.
+constexpr uint32_t BOOL_STEPS = 8;
+constexpr uint32_t BOOL_TILE = 128 * BOOL_STEPS;
+
 __global__ __launch_bounds__(256) void bool_expand_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const ByteRun *__restrict__ runs,
     const uint32_t *__restrict__ win_first, uint32_t n_win_slots, uint32_t n_runs,
     uint64_t num_bits, uint8_t *__restrict__ out_bytes, uint8_t *__restrict__ out_bitmap,
     unsigned long long *__restrict__ set_bits) {
     const uint64_t num_bytes = (num_bits + 7) >> 3;  // decoded bytes wanted
-    const uint64_t n_tiles = (num_bytes + 511) / 512;
+    const uint64_t n_tiles = (num_bytes + BOOL_TILE - 1) / BOOL_TILE;
     const uint32_t lane = threadIdx.x & 63;
     const bool bytes_aligned = (((uintptr_t)out_bytes) & 15) == 0;
     const bool bitmap_aligned = (((uintptr_t)out_bitmap) & 1) == 0;
     uint32_t ones = 0;
-    // grid-stride over tiles: the count of ones costs one atomic per wavefront
+    // Grid-stride over tiles: the count of ones costs one atomic per wavefront.  (Fetching the
+    // window index and the runs of the following tiles ahead of time measured no faster.)
     for (uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles;
          tile += (uint64_t)gridDim.x * 4) {
-        const uint64_t tile_base = tile * 512;
+        const uint64_t tile_base = tile * BOOL_TILE;
         // runs [r_lo, r_hi) overlap the tile: from the one that reaches into its first window to
         // the last one that starts before its end
         const uint64_t w0 = tile_base >> BR_WINDOW_SHIFT;
-        const uint64_t w1 = (w0 + 4 < n_win_slots) ? w0 + 4 : n_win_slots - 1;
+        const uint64_t w1 = (w0 + BOOL_STEPS < n_win_slots) ? w0 + BOOL_STEPS : n_win_slots - 1;
         uint32_t r_lo = __builtin_amdgcn_readfirstlane(win_first[w0]);
         uint32_t r_hi = __builtin_amdgcn_readfirstlane(win_first[w1]);
         if (r_hi > n_runs) r_hi = n_runs;
         r_lo = r_lo > 0 ? r_lo - 1 : 0;
         if (r_lo > r_hi) r_lo = r_hi;
-        // a tile whose 4096 values are all wanted needs no masking of a partial last byte
-        const bool full = (tile_base + 512) * 8 <= num_bits;
-        uint32_t mm[4];  // per step: this lane's two decoded bytes, the first in bits 0..7
+        // a tile whose values are all wanted needs no masking of a partial last byte
+        const bool full = (tile_base + BOOL_TILE) * 8 <= num_bits;
+        uint32_t mm[BOOL_STEPS];  // per step: this lane's two decoded bytes, the first in bits 0..7
         if (r_hi - r_lo <= 64) {
             // lane k holds run r_lo + k: its start relative to the tile (negative for a run that
             // began before it) and its source relative to the first run's
@@ -238,22 +245,41 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
             const uint32_t *sw = (const uint32_t *)(sb - skew);
             const uint64_t avail = len > src0 ? len - src0 : 0;  // stream bytes from src0 on
             const uint32_t lim = avail > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)avail;
-            uint32_t word_idx = 0xFFFFFFFFu, word = 0;
+            uint32_t boff[BOOL_STEPS][2];
 #pragma unroll
-            for (uint32_t step = 0; step < 4; step++) {
+            for (uint32_t step = 0; step < BOOL_STEPS; step++) {
                 const int32_t p = (int32_t)(128 * step + 2 * lane);
-                // largest k with rel[k] <= p (lanes past the last run hold INT_MAX; rel[0] <= 0)
-                int k = 0;
+                // The runs that hold the step's first and last byte: the starts ascend over the
+                // lanes, so the number of starts at or below a position is a ballot away.
+                const int32_t p_first = (int32_t)(128 * step);
+                const uint32_t kf = (uint32_t)__popcll(__ballot(my_rel <= p_first)) - 1u;
+                const uint32_t kl = (uint32_t)__popcll(__ballot(my_rel <= p_first + 127)) - 1u;
+                int32_t rel_k, rel_n;
+                uint32_t srel_k, srel_n;
+                if (kl <= kf + 1) {
+                    // at most two runs under the step (runs of a hundred bytes and more are the
+                    // common case): their fields are wave-uniform, no lane has to search
+                    const int a = __builtin_amdgcn_readfirstlane((int)kf), b = (a + 1) & 63;
+                    rel_k = __builtin_amdgcn_readlane(my_rel, a);
+                    rel_n = a == 63 ? 0x7FFFFFFF : __builtin_amdgcn_readlane(my_rel, b);
+                    srel_k = __builtin_amdgcn_readlane(my_srel, a);
+                    srel_n = __builtin_amdgcn_readlane(my_srel, b);
+                } else {
+                    // largest k with rel[k] <= p (lanes past the last run hold INT_MAX; rel[0] <= 0)
+                    int k = 0;
 #pragma unroll
-                for (int sft = 32; sft >= 1; sft >>= 1) {
-                    const int32_t v = __shfl(my_rel, k + sft);
-                    if (v <= p) k += sft;
+                    for (int sft = 32; sft >= 1; sft >>= 1) {
+                        const int32_t v = __shfl(my_rel, k + sft);
+                        if (v <= p) k += sft;
+                    }
+                    rel_k = __shfl(my_rel, k);
+                    rel_n = __shfl(my_rel, (k + 1) & 63);
+                    if (k == 63) rel_n = 0x7FFFFFFF;  // no run after the 64th
+                    srel_k = __shfl(my_srel, k);
+                    srel_n = __shfl(my_srel, (k + 1) & 63);
                 }
-                const int32_t rel_k = __shfl(my_rel, k);
-                int32_t rel_n = __shfl(my_rel, (k + 1) & 63);
-                if (k == 63) rel_n = 0x7FFFFFFF;  // no run after the 64th
-                const uint32_t srel_k = __shfl(my_srel, k), srel_n = __shfl(my_srel, (k + 1) & 63);
-                uint32_t two = 0;
+                // where this lane's two bytes lie, as byte offsets from the aligned dword at or
+                // before s + src0 (0xFFFFFFFF: past the stream, reads as zero)
 #pragma unroll
                 for (uint32_t h = 0; h < 2; h++) {
                     const int32_t q = p + (int32_t)h;
@@ -261,19 +287,29 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
                     const uint32_t srel = next ? srel_n : srel_k;
                     const int32_t rel = next ? rel_n : rel_k;
                     const uint32_t off = (srel & 0x7FFFFFFFu) + ((srel >> 31) ? 0u : (uint32_t)(q - rel));
-                    const uint32_t boff = off + skew;
-                    if (off < lim && (boff >> 2) != word_idx) {
-                        word_idx = boff >> 2;
-                        word = sw[word_idx];
-                    }
-                    const uint32_t byte = off < lim ? (word >> (8 * (boff & 3))) & 0xFFu : 0u;
-                    two |= byte << (8 * h);
+                    boff[step][h] = off < lim ? off + skew : 0xFFFFFFFFu;
                 }
-                mm[step] = two;
+            }
+            // all the tile's stream loads go out together (as aligned dwords: a byte-sized load
+            // costs the memory pipeline as much per lane), then the bytes are picked out
+            uint32_t word[BOOL_STEPS][2];
+#pragma unroll
+            for (uint32_t step = 0; step < BOOL_STEPS; step++) {
+                word[step][0] = boff[step][0] != 0xFFFFFFFFu ? sw[boff[step][0] >> 2] : 0u;
+                const bool same = (boff[step][1] >> 2) == (boff[step][0] >> 2);
+                word[step][1] = (!same && boff[step][1] != 0xFFFFFFFFu) ? sw[boff[step][1] >> 2] : 0u;
+            }
+#pragma unroll
+            for (uint32_t step = 0; step < BOOL_STEPS; step++) {
+                const bool same = (boff[step][1] >> 2) == (boff[step][0] >> 2);
+                const uint32_t w1 = same ? word[step][0] : word[step][1];
+                const uint32_t b0 = (word[step][0] >> (8 * (boff[step][0] & 3))) & 0xFFu;
+                const uint32_t b1 = (w1 >> (8 * (boff[step][1] & 3))) & 0xFFu;
+                mm[step] = b0 | (b1 << 8);
             }
         } else {
             RunCursor cur = {s, len, runs, n_runs, 0, {0, 0}, 0, 0};
-            for (uint32_t step = 0; step < 4; step++) {
+            for (uint32_t step = 0; step < BOOL_STEPS; step++) {
                 const uint64_t o = tile_base + 128 * step + 2 * lane;
                 mm[step] = 0;
                 if (o < num_bytes) {
@@ -284,7 +320,7 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
             }
         }
 #pragma unroll
-        for (uint32_t step = 0; step < 4; step++) {
+        for (uint32_t step = 0; step < BOOL_STEPS; step++) {
             const uint64_t o = tile_base + 128 * step + 2 * lane;
             uint32_t two = mm[step];
             if (!full) {
@@ -319,7 +355,11 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
                 const uint64_t first = o << 3;
                 uint8_t *dst = out_bytes + first;
                 if ((full || first + 16 <= num_bits) && bytes_aligned) {
-                    *(ulonglong2 *)dst = make_ulonglong2(word[0], word[1]);
+                    // written once, not read back here: keep it out of the way of the stream bytes
+                    u64x2 v;
+                    v.x = word[0];
+                    v.y = word[1];
+                    __builtin_nontemporal_store(v, (u64x2 *)dst);
                 } else {
                     for (uint32_t j = 0; j < 16 && first + j < num_bits; j++)
                         dst[j] = (uint8_t)(word[j >> 3] >> (8 * (j & 7)));
@@ -367,7 +407,7 @@ hipError_t launch_bool_expand(hipStream_t st, const uint8_t *stream, uint64_t le
                               uint8_t *out_bitmap, uint64_t *set_bits) {
     const uint64_t n_bytes = (num_bits + 7) >> 3;
     if (n_bytes == 0) return hipSuccess;
-    const uint64_t tiles = (n_bytes + 511) / 512;  // one per wavefront, four per workgroup
+    const uint64_t tiles = (n_bytes + BOOL_TILE - 1) / BOOL_TILE;  // one per wavefront, four per workgroup
     bool_expand_kernel<<<(uint32_t)std::min<uint64_t>((tiles + 3) / 4, BR_MAX_BLOCKS), 256, 0, st>>>(
         stream, len, runs, win_first, n_win_slots, n_runs, num_bits, out_bytes, out_bitmap,
         (unsigned long long *)set_bits);
