@@ -168,20 +168,72 @@ __device__ __forceinline__ uint32_t parse_run(const Window16 &w, const uint8_t *
     return SEG_OK;
 }
 
+// A lane's private stretch of stream bytes in LDS: where runs are short, the next few headers lie
+// within the bytes fetched for the current one, and parsing them from here saves the memory round
+// trip each would otherwise cost.
+constexpr uint32_t HB_WORDS = 12;   // 96 bytes
+constexpr uint32_t HB_STRIDE = 13;  // slice pitch in 8-byte words (odd: spreads the LDS banks)
+
+struct HeaderBuf {
+    uint64_t *slice;   // HB_WORDS words
+    uintptr_t base;    // address the first word was loaded from (8-byte aligned)
+    uint32_t words;    // how many are valid
+};
+
+// The 16-byte window at `pos` out of the lane's buffer, refilled from memory when the window is
+// not inside it: with 3 words (just this window) or, `wide`, with all HB_WORDS.
+__device__ __forceinline__ Window16 buffered_window(const uint8_t *s, uint64_t len, uint64_t pos,
+                                                    HeaderBuf &hb, bool wide) {
+    const uintptr_t a = (uintptr_t)(s + pos);
+    const uintptr_t a0 = a & ~(uintptr_t)7;
+    const uintptr_t end = (uintptr_t)(s + len);
+    const uint32_t sh = (uint32_t)(a & 7) * 8;
+    const uintptr_t idx = (a0 - hb.base) >> 3;  // huge when a0 lies before the buffer
+    uint64_t q0, q1, q2;
+    if (hb.words && a0 >= hb.base && idx + 3 <= hb.words) {
+        q0 = hb.slice[idx];
+        q1 = hb.slice[idx + 1];
+        q2 = hb.slice[idx + 2];
+    } else {
+        const uint32_t n = wide ? HB_WORDS : 3u;
+        const uint64_t *p = (const uint64_t *)a0;
+        uint64_t v[HB_WORDS];
+        // all loads are issued together; a word past the end is replaced by a re-read of the
+        // first one (select on the address, not on the load)
+#pragma unroll
+        for (uint32_t i = 0; i < HB_WORDS; i++)
+            v[i] = i < n ? *((a0 + 8 * i < end) ? p + i : p) : 0;
+#pragma unroll
+        for (uint32_t i = 0; i < HB_WORDS; i++)
+            if (i < n) hb.slice[i] = v[i];
+        hb.base = a0;
+        hb.words = n;
+        q0 = v[0];
+        q1 = v[1];
+        q2 = v[2];
+    }
+    Window16 w;
+    w.lo = sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0;
+    w.hi = sh ? (q1 >> sh) | (q2 << (64 - sh)) : q1;
+    return w;
+}
+
 // Walks the run headers of [pos, end), at most max_runs of them, calling consume(run) for each.
 // Headers form a serial chain -- a header's position is known only once its predecessor is
-// parsed -- so a plain walk pays one memory round trip per run.  Every round here loads the header
-// at `pos` together with three more at pos + k * (size of the previous run) and then parses as
-// many of the four as the chain confirms: in a long column most neighbouring runs have the same
-// size, and four headers then cost one round trip.  A wrong guess costs the extra loads, so the
-// guessing is switched on by two consecutive runs of equal size and off by the first that differs.
+// parsed -- so a plain walk pays one memory round trip per run.  Two ways around that:
+//  * long runs of equal size (the bulk of a long column): every round loads the header at `pos`
+//    together with three more at pos + k * (size of the previous run) and parses as many of the
+//    four as the chain confirms.  A wrong guess costs the extra loads, so the guessing is switched
+//    on by two consecutive runs of equal size and off by the first that differs;
+//  * short runs: the bytes fetched for one header hold the next ones too (buffered_window).
 template <typename Consume>
 __device__ __forceinline__ uint32_t walk_headers(const uint8_t *s, uint64_t len, uint64_t &pos,
                                                  uint64_t end, uint32_t max_runs, int is_signed,
-                                                 Consume &&consume) {
+                                                 uint64_t *lds_slice, Consume &&consume) {
     uint64_t stride = 0, prev_stride = ~0ull;
     uint32_t n = 0, status = SEG_OK;
     ParsedRun r;
+    HeaderBuf hb = {lds_slice, 0, 0};
     auto step = [&](const Window16 &w) -> bool {
         status = parse_run(w, s, len, pos, is_signed, r);
         if (status != SEG_OK) return false;
@@ -193,16 +245,16 @@ __device__ __forceinline__ uint32_t walk_headers(const uint8_t *s, uint64_t len,
         return true;
     };
     while (pos < end && n < max_runs) {
-        // guess only while the guesses come true: where runs differ in size (short mixed runs)
-        // the three extra loads per round would be the bulk of the scan's memory traffic
         const bool guess = stride != 0 && stride == prev_stride;
         const uint64_t p1 = pos + stride, p2 = p1 + stride, p3 = p2 + stride;
         const bool h1 = guess && p1 < end, h2 = h1 && p2 < end, h3 = h2 && p3 < end;
-        const Window16 w0 = load_window(s, len, pos);
         if (!h1) {
+            // fetch ahead only where the last run was short enough for the next header to be near
+            const Window16 w0 = buffered_window(s, len, pos, hb, stride <= 8 * (HB_WORDS - 3));
             if (!step(w0)) break;
             continue;
         }
+        const Window16 w0 = load_window(s, len, pos);
         const Window16 w1 = load_window(s, len, p1);
         const Window16 w2 = load_window(s, len, h2 ? p2 : pos);
         const Window16 w3 = load_window(s, len, h3 ? p3 : pos);
@@ -229,6 +281,8 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
     const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
     RunEntry *__restrict__ runs, uint32_t *__restrict__ group_first,
     RunEntry *__restrict__ group_run, uint32_t n_group_slots, int full_table) {
+    __shared__ uint64_t header_bytes[SEG_BLOCK * HB_STRIDE];
+    uint64_t *lds_slice = header_bytes + threadIdx.x * HB_STRIDE;
     const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
     const bool valid = seg < n_seg;
     // A segment runs from its entry to the next entry -- or, when seg_ends is given (slices of a
@@ -248,7 +302,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
         uint64_t n_vals = 0;
         if (end > len || end < pos) status = SEG_MISALIGNED;
         if (valid && status == SEG_OK) {
-            status = walk_headers(s, limit, pos, end, 0xFFFFFFFFu, is_signed, [&](const ParsedRun &r) {
+            status = walk_headers(s, limit, pos, end, 0xFFFFFFFFu, is_signed, lds_slice, [&](const ParsedRun &r) {
                 n_runs++;
                 n_vals += r.len;
                 last_len = r.len;
@@ -264,7 +318,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
         uint32_t run_idx = so.run_off;
         uint32_t prev_len = so.prev_len;  // 0 only before the very first run
         // the counting pass found n_runs well-formed runs from here
-        walk_headers(s, limit, pos, end, n_runs, is_signed, [&](const ParsedRun &r) {
+        walk_headers(s, limit, pos, end, n_runs, is_signed, lds_slice, [&](const ParsedRun &r) {
             RunEntry e;
             e.desc = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg);
             e.out_off = out_off;
