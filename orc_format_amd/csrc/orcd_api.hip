@@ -166,17 +166,17 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
     const uint64_t n_slots = ((sr.totals.total_vals + WINDOW - 1) >> WINDOW_SHIFT) + 1;
     if (n_slots > 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
     void *runs, *groups, *group_runs;
-    ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(RunEntry), &runs));
+    ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(uint64_t), &runs));
     ORCD_TRY(ensure(c, SLOT_GROUPS, (size_t)n_slots * sizeof(uint32_t), &groups));
     ORCD_TRY(ensure(c, SLOT_GROUP_RUNS, (size_t)n_slots * sizeof(RunEntry), &group_runs));
     HIP_TRY(c, launch_rlev2_emit(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, sr.table,
-                                 (RunEntry *)runs, (uint32_t *)groups, (RunEntry *)group_runs,
+                                 (uint64_t *)runs, (uint32_t *)groups, (RunEntry *)group_runs,
                                  (uint32_t)n_slots, full_table));
     mark(c, 2);
     const uint64_t covered = std::min<uint64_t>(num_values, sr.totals.total_vals);
     t->stream = d_stream;
     t->len = len;
-    t->runs = (const RunEntry *)runs;
+    t->runs = (const uint64_t *)runs;
     t->group_first = (const uint32_t *)groups;
     t->group_run = (const RunEntry *)group_runs;
     t->n_groups = (uint32_t)((covered + WINDOW - 1) >> WINDOW_SHIFT);
@@ -485,27 +485,27 @@ int orcd_rlev2_runs(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_v
     Rlev2Table t;
     ORCD_TRY(rlev2_table(c, (const uint8_t *)d_stream, len, num_values, (const uint64_t *)d_entries,
                          n_entries, (flags & ORCD_SIGNED) ? 1 : 0, &t, true));
-    RunEntry *h = new RunEntry[t.n_runs + 1];
-    hipError_t e = hipMemcpyAsync(h, t.runs, (t.n_runs + 1) * sizeof(RunEntry),
-                                  hipMemcpyDeviceToHost, c->stream);
+    std::vector<uint64_t> h((size_t)t.n_runs + 1);
+    hipError_t e = hipMemcpyAsync(h.data(), t.runs, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                  c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
-        delete[] h;
         c->last_hip = e;
         return ORCD_HIP_ERROR;
     }
     size_t count = 0;
-    for (uint64_t i = 0; i < t.n_runs && h[i].out_off < num_values; i++, count++) {
+    uint64_t out_off = 0;  // the table holds descriptors: a run starts where the lengths before it end
+    for (uint64_t i = 0; i < t.n_runs && out_off < num_values; i++, count++) {
         if (count < max_runs) {
-            runs[count].payload_offset = desc_payload(h[i].desc);
-            runs[count].out_offset = h[i].out_off;
-            runs[count].kind = desc_kind(h[i].desc);
-            runs[count].bit_width = desc_width(h[i].desc);
-            runs[count].length = desc_len(h[i].desc);
+            runs[count].payload_offset = desc_payload(h[i]);
+            runs[count].out_offset = out_off;
+            runs[count].kind = desc_kind(h[i]);
+            runs[count].bit_width = desc_width(h[i]);
+            runs[count].length = desc_len(h[i]);
             runs[count].reserved = 0;
         }
+        out_off += desc_len(h[i]);
     }
-    delete[] h;
     *n_runs = count;
     return ORCD_OK;
 }

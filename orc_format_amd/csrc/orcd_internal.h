@@ -9,16 +9,20 @@
 namespace orcd {
 
 // ---- RLE v2 run table -------------------------------------------------------------------------
-// Written by the header-scan kernel, read by the value kernel: everything the value kernel needs
-// is here, so it never parses a header.
+// Written by the header-scan kernel, read by the value kernel.
 //
-// desc bit layout
-//   [0,40)  payload_off   offset in the stream of the run's packed bytes
-//   [40,42) kind          0 ShortRepeat, 1 Direct, 2 PatchedBase, 3 Delta
-//   [42,49) width         packed bit width, 0..64
-//   [49,58) len - 1       run length 1..512
-//   58      delta_neg     Delta: the per-value deltas are subtracted
-//   59      single        (per-window copies only) no other run starts in the window
+// A run is one 64-bit descriptor:
+//   [0,39)  payload_off   offset in the stream of the run's packed bytes
+//   [39,41) kind          0 ShortRepeat, 1 Direct, 2 PatchedBase, 3 Delta
+//   [41,48) width         packed bit width, 0..64
+//   [48,57) len - 1       run length 1..512
+//   57      delta_neg     Delta: the per-value deltas are subtracted
+//   58      single        (per-window copies only) no other run starts in the window
+//   [59,64) header bytes  distance from the run's first header byte to payload_off (1..22)
+// The run table proper (`runs`) holds descriptors only: the value kernel gets a run's place in the
+// output from a prefix sum of the lengths and its base / second field by parsing the header again
+// (one lane per run, once).  The per-window copy of a window's first run (RunEntry) carries them
+// ready-made, so that a window that is one run -- the bulk of a long column -- needs nothing else.
 struct RunEntry {
     uint64_t desc;
     uint64_t out_off;  // index of the run's first value in the output
@@ -29,19 +33,21 @@ struct RunEntry {
 static_assert(sizeof(RunEntry) == 32, "RunEntry is read as two 16-byte loads");
 
 constexpr int KIND_SHORT_REPEAT = 0, KIND_DIRECT = 1, KIND_PATCHED_BASE = 2, KIND_DELTA = 3;
-constexpr uint64_t PAYLOAD_MASK = (1ull << 40) - 1;
-constexpr uint64_t DESC_SINGLE = 1ull << 59;
+constexpr uint64_t RUN_PAYLOAD_MASK = (1ull << 39) - 1;
+constexpr uint64_t DESC_SINGLE = 1ull << 58;
+constexpr uint64_t PAYLOAD_MASK = (1ull << 40) - 1;  // byte-RLE run table
 
 __host__ __device__ inline uint64_t make_desc(uint64_t payload_off, uint32_t kind, uint32_t width,
-                                              uint32_t len, uint32_t delta_neg) {
-    return (payload_off & PAYLOAD_MASK) | ((uint64_t)kind << 40) | ((uint64_t)width << 42) |
-           ((uint64_t)(len - 1) << 49) | ((uint64_t)delta_neg << 58);
+                                              uint32_t len, uint32_t delta_neg, uint32_t header_bytes) {
+    return (payload_off & RUN_PAYLOAD_MASK) | ((uint64_t)kind << 39) | ((uint64_t)width << 41) |
+           ((uint64_t)(len - 1) << 48) | ((uint64_t)delta_neg << 57) | ((uint64_t)header_bytes << 59);
 }
-__host__ __device__ inline uint64_t desc_payload(uint64_t d) { return d & PAYLOAD_MASK; }
-__host__ __device__ inline uint32_t desc_kind(uint64_t d) { return (uint32_t)(d >> 40) & 3u; }
-__host__ __device__ inline uint32_t desc_width(uint64_t d) { return (uint32_t)(d >> 42) & 127u; }
-__host__ __device__ inline uint32_t desc_len(uint64_t d) { return ((uint32_t)(d >> 49) & 511u) + 1u; }
-__host__ __device__ inline uint32_t desc_delta_neg(uint64_t d) { return (uint32_t)(d >> 58) & 1u; }
+__host__ __device__ inline uint64_t desc_payload(uint64_t d) { return d & RUN_PAYLOAD_MASK; }
+__host__ __device__ inline uint32_t desc_kind(uint64_t d) { return (uint32_t)(d >> 39) & 3u; }
+__host__ __device__ inline uint32_t desc_width(uint64_t d) { return (uint32_t)(d >> 41) & 127u; }
+__host__ __device__ inline uint32_t desc_len(uint64_t d) { return ((uint32_t)(d >> 48) & 511u) + 1u; }
+__host__ __device__ inline uint32_t desc_delta_neg(uint64_t d) { return (uint32_t)(d >> 57) & 1u; }
+__host__ __device__ inline uint32_t desc_header_bytes(uint64_t d) { return (uint32_t)(d >> 59) & 31u; }
 
 // PatchedBase geometry packed in RunEntry::aux:
 //   [0,7) patch width  [7,11) gap width  [11,16) patch list length  [16,23) packed entry width
@@ -103,7 +109,7 @@ hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t le
                               int is_signed, const SegTable &t);
 hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                              const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
-                             int is_signed, const SegTable &t, RunEntry *runs, uint32_t *group_first,
+                             int is_signed, const SegTable &t, uint64_t *runs, uint32_t *group_first,
                              RunEntry *group_run, uint32_t n_group_slots, bool full_table);
 hipError_t launch_seg_value_offsets(hipStream_t st, const SegTable &t, const uint32_t *first_seg,
                                     uint32_t n, uint64_t *out);
@@ -111,7 +117,7 @@ hipError_t launch_seg_value_offsets(hipStream_t st, const SegTable &t, const uin
 struct Rlev2Table {
     const uint8_t *stream;
     uint64_t len;
-    const RunEntry *runs;          // [n_runs + 1], the last one a sentinel
+    const uint64_t *runs;          // descriptors [n_runs + 1], the last one a sentinel
     const uint32_t *group_first;   // per window of 512 values: index of the first run starting in it
     const RunEntry *group_run;     // ... and a copy of that run, flagged when it is the only one
     uint32_t n_groups;             // windows that hold wanted values

@@ -87,7 +87,7 @@ __device__ __forceinline__ Window16 load_window(const uint8_t *s, uint64_t len, 
 
 struct ParsedRun {
     uint64_t payload_off, run_end, base, aux;
-    uint32_t kind, width, len, delta_neg;
+    uint32_t kind, width, len, delta_neg, header_bytes;
 };
 
 // LEB128 starting at byte `i` of the header window; bytes past the window come from memory.
@@ -163,8 +163,9 @@ __device__ __forceinline__ uint32_t parse_run(const Window16 &w, const uint8_t *
         r.payload_off = pos + 4 + base_bytes;
         r.run_end = r.payload_off + ((uint64_t)r.width * r.len + 7) / 8 + ((uint64_t)cfb * pll + 7) / 8;
     }
+    r.header_bytes = (uint32_t)(r.payload_off - pos);
     if (r.run_end > len) return SEG_TRUNCATED;
-    if (r.payload_off > PAYLOAD_MASK) return SEG_TOO_LONG;
+    if (r.payload_off > RUN_PAYLOAD_MASK) return SEG_TOO_LONG;
     return SEG_OK;
 }
 
@@ -279,7 +280,7 @@ template <bool EMIT>
 __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
     const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
-    RunEntry *__restrict__ runs, uint32_t *__restrict__ group_first,
+    uint64_t *__restrict__ runs, uint32_t *__restrict__ group_first,
     RunEntry *__restrict__ group_run, uint32_t n_group_slots, int full_table) {
     __shared__ uint64_t header_bytes[SEG_BLOCK * HB_STRIDE];
     uint64_t *lds_slice = header_bytes + threadIdx.x * HB_STRIDE;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
         // the counting pass found n_runs well-formed runs from here
         walk_headers(s, limit, pos, end, n_runs, is_signed, lds_slice, [&](const ParsedRun &r) {
             RunEntry e;
-            e.desc = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg);
+            e.desc = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes);
             e.out_off = out_off;
             e.base = r.base;
             e.aux = r.aux;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
             const bool single = first && ((out_off + r.len) >> WINDOW_SHIFT) != win;
             // The value kernels read a single-run window's run from group_run only: its slot in
             // the run table stays unwritten unless the table itself is what the caller wants.
-            if (!single || full_table) runs[run_idx] = e;
+            if (!single || full_table) runs[run_idx] = e.desc;
             if (first && win < n_group_slots) {
                 group_first[win] = run_idx;
                 // the window's own copy, so that the value kernel needs no dependent table load
@@ -345,11 +346,11 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
         if (last_seg) {
             // sentinel: one-past-the-end run and the window after the last value
             RunEntry e;
-            e.desc = make_desc(pos, KIND_SHORT_REPEAT, 0, 1, 0);
+            e.desc = make_desc(pos, KIND_SHORT_REPEAT, 0, 1, 0, 1);
             e.out_off = out_off;
             e.base = 0;
             e.aux = 0;
-            runs[run_idx] = e;
+            runs[run_idx] = e.desc;
             // Windows in which no run starts exist only at the tail: the last run may reach
             // into one more window.  They, and the slot one past the last window, get the
             // sentinel's index (an empty group).
@@ -875,24 +876,38 @@ struct RunFields {
     uint32_t rel_out;  // out_off relative to the batch's first value
 };
 
+// `batch_beg`: index in the output of the batch's first value.  Returns the index after its last.
 template <class W>
-__device__ __forceinline__ void decode_run_batch(const W &wv, const RunEntry *runs, uint32_t rb,
-                                                 uint32_t nb) {
+__device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t *runs, uint32_t rb,
+                                                     uint32_t nb, const uint64_t batch_beg) {
     const int lane = wv.lane;
-    // lane k holds run rb + k of the batch
+    // lane k holds run rb + k of the batch: its descriptor from the table, its place in the
+    // output from a prefix sum of the lengths, its base / second field from its header
     RunEntry me;
-    me.desc = make_desc(0, KIND_SHORT_REPEAT, 0, 1, 0);
-    me.out_off = ~0ull;
+    me.desc = make_desc(0, KIND_SHORT_REPEAT, 0, 1, 0, 1);
     me.base = 0;
     me.aux = 0;
-    if ((uint32_t)lane < nb) me = runs[rb + lane];
+    const bool mine = (uint32_t)lane < nb;
+    if (mine) me.desc = runs[rb + lane];
     const uint32_t my_kind = desc_kind(me.desc), my_w = desc_width(me.desc);
     const uint32_t my_len = desc_len(me.desc);
-    const uint64_t batch_beg = readlane64(me.out_off, 0);
-    uint64_t batch_end = readlane64(me.out_off + my_len, (int)nb - 1);
-    if (batch_end > wv.num_values) batch_end = wv.num_values;
-    if (batch_beg >= batch_end) return;  // every run of the batch lies after the last wanted value
-    const uint32_t my_rel = (uint32_t)lane < nb ? (uint32_t)(me.out_off - batch_beg) : 0xFFFFFFFFu;
+    const uint32_t incl = wave_scan_u32(mine ? my_len : 0u, lane);
+    const uint32_t my_rel = mine ? incl - my_len : 0xFFFFFFFFu;
+    me.out_off = mine ? batch_beg + my_rel : ~0ull;
+    const uint64_t batch_all = batch_beg + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint64_t batch_end = batch_all < wv.num_values ? batch_all : wv.num_values;
+    if (batch_beg >= batch_end) return batch_all;  // every run of the batch lies after the last wanted value
+    if (mine && my_kind != KIND_DIRECT) {
+        // the header scan accepted this header: the parse cannot fail, and reads what it read
+        const uint64_t pos = desc_payload(me.desc) - desc_header_bytes(me.desc);
+        ParsedRun r;
+        r.base = 0;
+        r.aux = 0;
+        if (pos < wv.len && parse_run(load_window(wv.s, wv.len, pos), wv.s, wv.len, pos, wv.is_signed, r) == SEG_OK) {
+            me.base = r.base;
+            me.aux = r.aux;
+        }
+    }
     uint64_t carry = 0;  // running value of a Delta run that continues into the next step
 
     for (uint64_t wbase = (batch_beg >> WINDOW_SHIFT) << WINDOW_SHIFT; wbase < batch_end;
@@ -1048,6 +1063,7 @@ __device__ __forceinline__ void decode_run_batch(const W &wv, const RunEntry *ru
                           readlane64(me.out_off, k));
         }
     }
+    return batch_all;
 }
 
 // MODE_SUMS: group_sums[g] receives the (saturating) sum of the values of the runs that start in
@@ -1056,7 +1072,7 @@ __device__ __forceinline__ void decode_run_batch(const W &wv, const RunEntry *ru
 // receives the sum of the values before i.
 template <int MODE>
 __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
-    const uint8_t *__restrict__ s, uint64_t len, const RunEntry *__restrict__ runs,
+    const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ runs,
     const uint32_t *__restrict__ group_first, const RunEntry *__restrict__ group_run,
     uint32_t n_groups, uint32_t n_runs, uint64_t num_values, int is_signed,
     int64_t *__restrict__ out, uint64_t *__restrict__ group_sums, uint32_t *__restrict__ flags) {
@@ -1100,9 +1116,10 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
         if (r1 > n_runs) r1 = n_runs;
         uint32_t r0 = __builtin_amdgcn_readfirstlane(group_first[g]);
         if (r0 > r1) r0 = r1;
+        uint64_t beg = readfirstlane64(e->out_off);  // where the group's first run starts
         for (uint32_t rb = r0; rb < r1; rb += 64) {
             const uint32_t nb = (r1 - rb) < 64u ? (r1 - rb) : 64u;
-            decode_run_batch(wv, runs, rb, nb);
+            beg = decode_run_batch(wv, runs, rb, nb, beg);
         }
     }
     if (MODE == MODE_SUMS) {
@@ -1136,7 +1153,7 @@ hipError_t launch_block_totals_scan(hipStream_t st, const SegTable &t, uint32_t 
 
 hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                              const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
-                             int is_signed, const SegTable &t, RunEntry *runs, uint32_t *group_first,
+                             int is_signed, const SegTable &t, uint64_t *runs, uint32_t *group_first,
                              RunEntry *group_run, uint32_t n_group_slots, bool full_table) {
     const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
     rlev2_scan_kernel<true><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, seg_ends, n_seg,
