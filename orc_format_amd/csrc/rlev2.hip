@@ -893,7 +893,6 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
     const uint32_t my_len = desc_len(me.desc);
     const uint32_t incl = wave_scan_u32(mine ? my_len : 0u, lane);
     const uint32_t my_rel = mine ? incl - my_len : 0xFFFFFFFFu;
-    me.out_off = mine ? batch_beg + my_rel : ~0ull;
     const uint64_t batch_all = batch_beg + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     uint64_t batch_end = batch_all < wv.num_values ? batch_all : wv.num_values;
     if (batch_beg >= batch_end) return batch_all;  // every run of the batch lies after the last wanted value
@@ -918,10 +917,12 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
         // ---- which payload bytes does this window need? -----------------------------------
         uint64_t need_b0 = 0, need_b1 = 0;
         bool needs = false, scans = false;
-        if ((uint32_t)lane < nb && me.out_off < hi && me.out_off + my_len > lo &&
+        // (positions relative to the batch's first value fit 32 bits: 64 runs of at most 512)
+        const uint32_t lo_rel = (uint32_t)(lo - batch_beg), hi_rel = (uint32_t)(hi - batch_beg);
+        if ((uint32_t)lane < nb && my_rel < hi_rel && my_rel + my_len > lo_rel &&
             my_kind != KIND_SHORT_REPEAT && my_w != 0) {
-            const uint32_t first = me.out_off >= lo ? 0u : (uint32_t)(lo - me.out_off);
-            const uint32_t last = (me.out_off + my_len) <= hi ? my_len : (uint32_t)(hi - me.out_off);
+            const uint32_t first = my_rel >= lo_rel ? 0u : lo_rel - my_rel;
+            const uint32_t last = (my_rel + my_len) <= hi_rel ? my_len : hi_rel - my_rel;
             uint64_t b0, b1;
             payload_range(my_kind, my_w, first, last, b0, b1);
             needs = b1 > b0;
@@ -1060,7 +1061,7 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
             const int k = __ffsll((unsigned long long)pb_mask) - 1;
             pb_mask &= pb_mask - 1;
             apply_patches(wv, readlane64(me.desc, k), readlane64(me.base, k), readlane64(me.aux, k),
-                          readlane64(me.out_off, k));
+                          batch_beg + (uint32_t)__builtin_amdgcn_readlane((int)my_rel, k));
         }
     }
     return batch_all;
