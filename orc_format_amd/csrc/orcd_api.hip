@@ -144,6 +144,45 @@ int count_and_scan(orcd_ctx *c, uint32_t n_seg, uint64_t num_values, CountFn cou
 
 uint32_t segments_for(size_t n_entries) { return n_entries ? (uint32_t)n_entries : 1u; }
 
+// Entry points for a long stream that came without any: stretches of equal-sized runs are
+// confirmed in parallel (launch_rlev2_verify_stride) and cut every ENTRY_RUNS runs; whatever does
+// not follow the pattern is left to the last segment's serial walk.  Only a matter of speed: the
+// header scan validates every segment whatever the entries are.
+constexpr uint64_t GUESS_MIN_BYTES = 1u << 18;
+constexpr uint64_t ENTRY_RUNS = 32;
+constexpr int GUESS_MAX_ROUNDS = 48;
+
+int guess_entry_points(orcd_ctx *c, const uint8_t *d_stream, size_t len, int is_signed,
+                       std::vector<uint64_t> &entries) {
+    void *d_tmp;
+    ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &d_tmp));
+    uint64_t *d_word = (uint64_t *)d_tmp;
+    uint64_t p = 0;
+    entries.clear();
+    entries.push_back(0);
+    for (int round = 0; round < GUESS_MAX_ROUNDS && p < len; round++) {
+        HIP_TRY(c, launch_rlev2_probe(c->stream, d_stream, len, p, is_signed, d_word));
+        HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_word, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const uint64_t stride = c->h_scalars[0];
+        if (stride == 0) break;  // not a header: the scan will say what is wrong
+        const uint64_t n = (len - p) / stride;
+        c->h_scalars[1] = n;
+        HIP_TRY(c, hipMemcpyAsync(d_word, c->h_scalars + 1, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, launch_rlev2_verify_stride(c->stream, d_stream, len, p, stride, n, is_signed, d_word));
+        HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_word, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const uint64_t good = c->h_scalars[0];  // runs p, p + stride, ... confirmed
+        if (good == 0) break;
+        if (p != entries.back()) entries.push_back(p);
+        for (uint64_t k = ENTRY_RUNS; k < good; k += ENTRY_RUNS) entries.push_back(p + k * stride);
+        p += good * stride;
+        if (good < ENTRY_RUNS && round >= 8) break;  // no long stretches here: stop paying a round per few runs
+    }
+    if (p < len && p != entries.back()) entries.push_back(p);  // the rest: one serial segment
+    return ORCD_OK;
+}
+
 // Builds the run table of one RLE v2 stream that is already on the device.  d_seg_ends (nullable):
 // the end of every segment, for slices of a larger buffer decoded as one stream; seg_table
 // (nullable) receives the segment prefix sums for the caller's own checks.
@@ -152,6 +191,16 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
                 bool full_table = false, const uint64_t *d_seg_ends = nullptr,
                 SegTable *seg_table = nullptr) {
     if (n_entries > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
+    std::vector<uint64_t> guessed;
+    if (n_entries == 0 && len >= GUESS_MIN_BYTES) {
+        ORCD_TRY(guess_entry_points(c, d_stream, len, is_signed, guessed));
+        if (guessed.size() > 1 && guessed.size() <= 0xFFFFFFFFull) {
+            const void *d;
+            ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, guessed.data(), guessed.size() * sizeof(uint64_t), false, &d));
+            d_entries = (const uint64_t *)d;
+            n_entries = guessed.size();
+        }
+    }
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
     const uint64_t *seg_ends = n_entries ? d_seg_ends : nullptr;

@@ -111,6 +111,13 @@ hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len
                              const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                              int is_signed, const SegTable &t, uint64_t *runs, uint32_t *group_first,
                              RunEntry *group_run, uint32_t n_group_slots, bool full_table);
+// Parallel check of a guessed header chain (see rlev2.hip): the size of the run at `pos`, and the
+// first k < n for which p + k * stride is not the header of a run of `stride` bytes (*first_fail
+// must hold n or more beforehand).
+hipError_t launch_rlev2_probe(hipStream_t st, const uint8_t *stream, uint64_t len, uint64_t pos,
+                              int is_signed, uint64_t *out);
+hipError_t launch_rlev2_verify_stride(hipStream_t st, const uint8_t *stream, uint64_t len, uint64_t p,
+                                      uint64_t stride, uint64_t n, int is_signed, uint64_t *first_fail);
 hipError_t launch_seg_value_offsets(hipStream_t st, const SegTable &t, const uint32_t *first_seg,
                                     uint32_t n, uint64_t *out);
 // What the header scan leaves for the value kernels of one stream.

@@ -1163,6 +1163,51 @@ hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Entry points for a stream that comes without any.  The header chain is serial, but in a long
+// column most runs have the same size (512 values of one width), and that can be checked in
+// parallel: if the run at p + k * S parses and ends at p + (k + 1) * S for every k < j, and the
+// header at p is real, then by induction all of them are real headers.
+// ---------------------------------------------------------------------------------------------
+
+// out[0] = size in bytes of the run whose header is at pos (0 if it does not parse)
+__global__ void rlev2_probe_kernel(const uint8_t *__restrict__ s, uint64_t len, uint64_t pos,
+                                   int is_signed, uint64_t *__restrict__ out) {
+    if (blockIdx.x || threadIdx.x) return;
+    ParsedRun r;
+    uint64_t size = 0;
+    if (pos < len && parse_run(load_window(s, len, pos), s, len, pos, is_signed, r) == SEG_OK)
+        size = r.run_end - pos;
+    out[0] = size;
+}
+
+// *first_fail = smallest k < n for which the bytes at p + k * stride are not a run of `stride` bytes
+__global__ __launch_bounds__(256) void rlev2_verify_stride_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, uint64_t p, uint64_t stride, uint64_t n,
+    int is_signed, unsigned long long *__restrict__ first_fail) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t pos = p + k * stride;
+    ParsedRun r;
+    const bool ok = pos < len && parse_run(load_window(s, len, pos), s, len, pos, is_signed, r) == SEG_OK &&
+                    r.run_end - pos == stride;
+    if (!ok) atomicMin(first_fail, (unsigned long long)k);
+}
+
+hipError_t launch_rlev2_probe(hipStream_t st, const uint8_t *stream, uint64_t len, uint64_t pos,
+                              int is_signed, uint64_t *out) {
+    rlev2_probe_kernel<<<1, 64, 0, st>>>(stream, len, pos, is_signed, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_rlev2_verify_stride(hipStream_t st, const uint8_t *stream, uint64_t len, uint64_t p,
+                                      uint64_t stride, uint64_t n, int is_signed, uint64_t *first_fail) {
+    if (n == 0) return hipSuccess;
+    rlev2_verify_stride_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(
+        stream, len, p, stride, n, is_signed, (unsigned long long *)first_fail);
+    return hipGetLastError();
+}
+
 // out[i] = number of values before segment first_seg[i] (after the scan of the counts)
 __global__ void seg_value_offsets_kernel(SegTable t, const uint32_t *__restrict__ first_seg, uint32_t n,
                                          uint64_t *__restrict__ out) {

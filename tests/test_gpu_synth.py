@@ -89,3 +89,49 @@ def test_byte_rle_generator(oracle, run_fraction):
                 got_bits = np.unpackbits(bm[(skew & 1):(skew & 1) + nb], bitorder="little")[:num_bits]
                 assert (got_bits == want.cpu().numpy()).all()
                 assert bm[(skew & 1) + nb] == 0xEE
+
+
+def test_long_streams_without_entry_points(oracle):
+    """Streams long enough for the decoder to look for entry points of its own (stretches of
+    equal-sized runs confirmed in parallel): uniform, uniform with breaks, and not uniform at all."""
+    import torch
+    from bench_util import synth
+    from orc_format_amd import default_context
+    ctx = default_context()
+    a = synth.direct_w17(1500, seed=1, device="cuda")
+    b = synth.delta_monotonic(900, width=10, seed=2, device="cuda")
+    c = synth.direct_w17(37, seed=3, device="cuda")
+    d = synth.delta_monotonic(1100, width=16, seed=4, device="cuda")
+    m = synth.mixed_short_runs(40000, seed=5, device="cuda")
+    cases = {
+        "uniform": [a],
+        "breaks": [a, b, c, d, c, a],
+        "short runs": [(m[0], m[1], m[2])],
+        "short then uniform": [(m[0], m[1], m[2]), a, b],
+    }
+    for name, parts in cases.items():
+        signed = name in ("uniform", "breaks")
+        stream = torch.cat([p[0] for p in parts])
+        assert stream.numel() > (1 << 18)
+        n = sum(int(p[2].numel()) for p in parts)
+        rc, ref, _ = oracle.rlev2(stream.cpu().numpy(), n, signed)
+        assert rc == 0
+        want = torch.from_numpy(ref).cuda()
+        out = torch.empty(n, dtype=torch.int64, device="cuda")
+        for count in (n, n - 1000):
+            out.fill_(-7)
+            ctx.rlev2_device(stream.data_ptr(), stream.numel(), count, signed, out.data_ptr(), 0, 0)
+            ctx.synchronize()
+            assert torch.equal(out[:count], want[:count]), (name, count)
+            assert (out[count:] == -7).all()
+        # damaged in the middle of a uniform stretch: an error, not a crash and not wrong values
+        bad = stream.clone()
+        bad[stream.numel() // 2] ^= 0x40
+        rc_bad, ref_bad, _ = oracle.rlev2(bad.cpu().numpy(), n, signed)
+        from orc_format_amd.error import OrcError
+        try:
+            ctx.rlev2_device(bad.data_ptr(), bad.numel(), n, signed, out.data_ptr(), 0, 0)
+            ctx.synchronize()
+            assert rc_bad == 0 and torch.equal(out, torch.from_numpy(ref_bad).cuda()), name
+        except OrcError:
+            assert rc_bad != 0, name
