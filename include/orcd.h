@@ -129,6 +129,16 @@ int orcd_rlev2_decode_batch(orcd_ctx *ctx, const uint8_t *buffer, size_t buffer_
                             const orcd_rlev2_slice *slices, size_t n_slices, int64_t *out,
                             size_t *bad_slice, unsigned flags);
 
+/* The same for boolean streams (PRESENT, boolean DATA): `num_values` of a slice counts values
+ * (bits).  Every stream fills whole bytes, so the values of slice i are written from
+ * out_bytes + 8 * (sum of ceil(num_values / 8) of the slices before i) on, one byte (0 / 1) each;
+ * out_bytes needs 8 * (that sum over all slices) bytes, and the up to 7 bytes between the values
+ * of two slices are padding.  set_bits (HOST pointer, nullable) receives the number of true
+ * values of every slice. */
+int orcd_boolean_decode_batch(orcd_ctx *ctx, const uint8_t *buffer, size_t buffer_len,
+                              const orcd_rlev2_slice *slices, size_t n_slices, uint8_t *out_bytes,
+                              uint64_t *set_bits, size_t *bad_slice, unsigned flags);
+
 /* One decoded run header as SignedRleV2RunIter / UnsignedRleV2RunIter expose it
  * (src/read/decode/rle_v2.rs:432-439, 629-636: the Direct / Delta / ShortRepeat variants and
  * their len()). */

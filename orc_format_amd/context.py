@@ -234,6 +234,28 @@ class Context:
         check(rc, self._h)
         return out
 
+    def boolean_batch(self, buffer, slices):
+        """orcd_boolean_decode_batch on host buffers.  `slices`: (offset, length, num_bits,
+        entry_points or None).  Returns (list of bool arrays, one per slice; list of set-bit counts)."""
+        arr = (N.Rlev2Slice * len(slices))()
+        keep = []
+        starts, pos = [], 0
+        for i, (off, ln, nv, ent) in enumerate(slices):
+            e, ne = _entries(ent)
+            keep.append(e)
+            arr[i] = N.Rlev2Slice(off, ln, nv, e.ctypes.data if ne else None, ne)
+            starts.append(pos)
+            pos += 8 * ((nv + 7) // 8)
+        b = _host_u8(buffer)
+        out = np.empty(max(pos, 1), dtype=np.uint8)
+        counts = (C.c_uint64 * len(slices))()
+        bad = C.c_size_t(0)
+        rc = self._lib.orcd_boolean_decode_batch(self._h, b.ctypes.data, b.size, arr, len(slices),
+                                                 out.ctypes.data, counts, C.byref(bad), 0)
+        self.bad_slice = bad.value
+        check(rc, self._h)
+        return ([out[s:s + sl[2]].astype(bool) for s, sl in zip(starts, slices)], list(counts))
+
     # ---- device-pointer calls (raw addresses) -------------------------------------------------
     def rlev2_device(self, stream_ptr, length, num_values, signed, out_ptr, entries_ptr=0,
                      n_entries=0):

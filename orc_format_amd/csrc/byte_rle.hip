@@ -28,13 +28,17 @@ size_t byte_rle_window_slots(uint64_t total_bytes) {
 template <bool EMIT>
 __global__ __launch_bounds__(SEG_BLOCK) void byte_rle_scan_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
-    uint32_t n_seg, SegTable t, ByteRun *__restrict__ runs, uint32_t *__restrict__ win_first,
-    uint32_t n_win_slots) {
+    const uint64_t *__restrict__ seg_ends, uint32_t n_seg, SegTable t, ByteRun *__restrict__ runs,
+    uint32_t *__restrict__ win_first, uint32_t n_win_slots) {
     const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
     const bool valid = seg < n_seg;
     if (EMIT && !valid) return;
-    uint64_t pos = (valid && entries && seg > 0) ? entries[seg] : 0;
-    const uint64_t end = (valid && entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
+    // seg_ends (nullable): the segments are slices of a larger buffer, each a stream of its own
+    // that ends where it says (see the RLE v2 header scan)
+    uint64_t pos = (valid && entries && (seg > 0 || seg_ends)) ? entries[seg] : 0;
+    uint64_t end = (valid && entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
+    if (valid && seg_ends) end = seg_ends[seg];
+    const uint64_t limit = seg_ends ? (end < len ? end : len) : len;
     const bool last_seg = seg + 1 == n_seg;
     if (pos > len) pos = len;
     uint32_t n_runs = 0, status = SEG_OK, last_len = 0;
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void byte_rle_scan_kernel(
             next = pos + 1 + n;
             src = pos + 1;
         }
-        if (next > len) { status = SEG_TRUNCATED; break; }
+        if (next > limit) { status = SEG_TRUNCATED; break; }
         if (pos + 1 > PAYLOAD_MASK) { status = SEG_TOO_LONG; break; }
         if (EMIT) {
             ByteRun r;
@@ -377,17 +381,51 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
 constexpr uint64_t BR_MAX_BLOCKS = 256 * 16;  // workgroups of the expansion: 16 per CU
 
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                 const uint64_t *entries, uint32_t n_seg, const SegTable &t) {
+                                 const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
+                                 const SegTable &t) {
     byte_rle_scan_kernel<false><<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(
-        stream, len, entries, n_seg, t, nullptr, nullptr, 0);
+        stream, len, entries, seg_ends, n_seg, t, nullptr, nullptr, 0);
     return hipGetLastError();
 }
 
 hipError_t launch_byte_rle_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                const uint64_t *entries, uint32_t n_seg, const SegTable &t,
-                                ByteRun *runs, uint32_t *win_first, uint32_t n_win_slots) {
+                                const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
+                                const SegTable &t, ByteRun *runs, uint32_t *win_first,
+                                uint32_t n_win_slots) {
     byte_rle_scan_kernel<true><<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(
-        stream, len, entries, n_seg, t, runs, win_first, n_win_slots);
+        stream, len, entries, seg_ends, n_seg, t, runs, win_first, n_win_slots);
+    return hipGetLastError();
+}
+
+// out[i] = number of non-zero bytes among bytes[start[i] .. start[i] + count[i]): one workgroup
+// per slice (the set bits of every column of a batch of boolean streams)
+__global__ __launch_bounds__(256) void count_nonzero_slices_kernel(
+    const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ start,
+    const uint64_t *__restrict__ count, uint64_t *__restrict__ out) {
+    __shared__ uint64_t partial[4];
+    const uint8_t *p = bytes + start[blockIdx.x];
+    const uint64_t n = count[blockIdx.x];
+    uint64_t c = 0;
+    const bool aligned = (((uintptr_t)p) & 3) == 0;
+    const uint64_t n4 = aligned ? n / 4 : 0;
+    for (uint64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+        const uint32_t d = ((const uint32_t *)p)[i];
+        c += __popc(((d | ((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u);
+    }
+    for (uint64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) c += p[i] != 0;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = __shfl_down((uint32_t)c, d), hi = __shfl_down((uint32_t)(c >> 32), d);
+        c += ((uint64_t)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = partial[0] + partial[1] + partial[2] + partial[3];
+}
+
+hipError_t launch_count_nonzero_slices(hipStream_t st, const uint8_t *bytes, const uint64_t *start,
+                                       const uint64_t *count, uint32_t n_slices, uint64_t *out) {
+    if (n_slices == 0) return hipSuccess;
+    count_nonzero_slices_kernel<<<n_slices, 256, 0, st>>>(bytes, start, count, out);
     return hipGetLastError();
 }
 

@@ -254,15 +254,18 @@ struct ByteRleTable {
 
 // Builds the run table of one byte-RLE stream that is already on the device.
 int byte_rle_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_bytes,
-                   const uint64_t *d_entries, size_t n_entries, ByteRleTable *t) {
+                   const uint64_t *d_entries, size_t n_entries, ByteRleTable *t,
+                   const uint64_t *d_seg_ends = nullptr, SegTable *seg_table = nullptr) {
     if (n_entries > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
+    const uint64_t *seg_ends = n_entries ? d_seg_ends : nullptr;
     ScanResult sr;
     ORCD_TRY(count_and_scan(c, n_seg, num_bytes, [&](const SegTable &st) {
-        return launch_byte_rle_count(c->stream, d_stream, len, entries, n_seg, st);
+        return launch_byte_rle_count(c->stream, d_stream, len, entries, seg_ends, n_seg, st);
     }, &sr));
     mark(c, 1);
+    if (seg_table) *seg_table = sr.table;
     if (sr.totals.error) return (int)sr.totals.error;
     if (sr.totals.total_runs >= 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
     const size_t n_slots = byte_rle_window_slots(sr.totals.total_vals);
@@ -270,7 +273,7 @@ int byte_rle_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_
     void *runs, *wins;
     ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(ByteRun), &runs));
     ORCD_TRY(ensure(c, SLOT_GROUPS, n_slots * sizeof(uint32_t), &wins));
-    HIP_TRY(c, launch_byte_rle_emit(c->stream, d_stream, len, entries, n_seg, sr.table,
+    HIP_TRY(c, launch_byte_rle_emit(c->stream, d_stream, len, entries, seg_ends, n_seg, sr.table,
                                     (ByteRun *)runs, (uint32_t *)wins, (uint32_t)n_slots));
     mark(c, 2);
     t->runs = (const ByteRun *)runs;
@@ -432,27 +435,32 @@ int orcd_rlev2_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num
     return ORCD_OK;
 }
 
-int orcd_rlev2_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_len,
-                            const orcd_rlev2_slice *slices, size_t n_slices, int64_t *out,
-                            size_t *bad_slice, unsigned flags) {
-    if (bad_slice) *bad_slice = (size_t)-1;
-    if (!c || (buffer_len && !buffer) || (n_slices && !slices)) return ORCD_INVALID_ARGUMENT;
-    // One segment list over all slices: a slice starts a segment, and so does each of its entry
-    // points; every segment ends where the next one of its slice starts, or with the slice.
+}  // extern "C"
+
+namespace {
+
+// The slices of a batch as one segment list: a slice starts a segment, and so does each of its
+// entry points; every segment ends where the next one of its slice starts, or with the slice.
+// `units` of a slice = decoded items it must hold (values; for boolean streams bytes of 8 values).
+struct SegmentPlan {
     std::vector<uint64_t> starts, ends;
-    std::vector<uint32_t> first_seg;
-    std::vector<uint64_t> want_off;
-    std::vector<size_t> slice_of;
-    uint64_t total_values = 0;
+    std::vector<uint32_t> first_seg;   // per live slice: its first segment
+    std::vector<uint64_t> want_off;    // ... and the units before it
+    std::vector<size_t> slice_of;      // ... and its index in the caller's array
+    uint64_t total_units = 0;
+};
+
+int plan_segments(const orcd_rlev2_slice *slices, size_t n_slices, size_t buffer_len, bool bits,
+                  SegmentPlan &plan, size_t *bad_slice) {
     for (size_t i = 0; i < n_slices; i++) {
         const orcd_rlev2_slice &sl = slices[i];
         if (sl.offset > buffer_len || sl.length > buffer_len - sl.offset || (sl.n_entries && !sl.entry_points))
             return ORCD_INVALID_ARGUMENT;
         if (sl.num_values == 0) continue;
-        first_seg.push_back((uint32_t)starts.size());
-        want_off.push_back(total_values);
-        slice_of.push_back(i);
-        starts.push_back(sl.offset);
+        plan.first_seg.push_back((uint32_t)plan.starts.size());
+        plan.want_off.push_back(plan.total_units);
+        plan.slice_of.push_back(i);
+        plan.starts.push_back(sl.offset);
         uint64_t prev = 0;
         for (size_t j = 1; j < sl.n_entries; j++) {  // the first entry is the start of the slice
             const uint64_t e = sl.entry_points[j];
@@ -460,24 +468,61 @@ int orcd_rlev2_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_le
                 if (bad_slice) *bad_slice = i;
                 return ORCD_OUT_OF_SPEC;
             }
-            ends.push_back(sl.offset + e);
-            starts.push_back(sl.offset + e);
+            plan.ends.push_back(sl.offset + e);
+            plan.starts.push_back(sl.offset + e);
             prev = e;
         }
-        ends.push_back(sl.offset + sl.length);
-        total_values += sl.num_values;
+        plan.ends.push_back(sl.offset + sl.length);
+        plan.total_units += bits ? (sl.num_values + 7) / 8 : sl.num_values;
     }
+    return plan.starts.size() > 0xFFFFFFFFull ? ORCD_INVALID_ARGUMENT : ORCD_OK;
+}
+
+// Decoded as one stream, the items of a slice land where they belong only if every slice before
+// it holds exactly what it was said to hold: compares the scan's offsets at the slice starts
+// with the prefix sums of the counts.
+int verify_slice_offsets(orcd_ctx *c, const SegTable &seg, const SegmentPlan &plan, const uint32_t *d_first,
+                         size_t *bad_slice) {
+    void *d_val_off;
+    ORCD_TRY(ensure(c, SLOT_TMP, plan.first_seg.size() * sizeof(uint64_t), &d_val_off));
+    std::vector<uint64_t> got_off(plan.first_seg.size());
+    HIP_TRY(c, launch_seg_value_offsets(c->stream, seg, d_first, (uint32_t)plan.first_seg.size(),
+                                        (uint64_t *)d_val_off));
+    HIP_TRY(c, hipMemcpyAsync(got_off.data(), d_val_off, got_off.size() * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < got_off.size(); k++) {
+        if (got_off[k] != plan.want_off[k]) {  // slice k - 1 is the first that is off
+            if (bad_slice) *bad_slice = plan.slice_of[k ? k - 1 : 0];
+            return ORCD_OUT_OF_SPEC;
+        }
+    }
+    return ORCD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orcd_rlev2_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_len,
+                            const orcd_rlev2_slice *slices, size_t n_slices, int64_t *out,
+                            size_t *bad_slice, unsigned flags) {
+    if (bad_slice) *bad_slice = (size_t)-1;
+    if (!c || (buffer_len && !buffer) || (n_slices && !slices)) return ORCD_INVALID_ARGUMENT;
+    SegmentPlan plan;
+    ORCD_TRY(plan_segments(slices, n_slices, buffer_len, false, plan, bad_slice));
+    const uint64_t total_values = plan.total_units;
     if (total_values == 0) return ORCD_OK;
-    if (!out || starts.size() > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
+    if (!out) return ORCD_INVALID_ARGUMENT;
     DeviceGuard g(c->device);
     reset_events(c);
     const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
     mark(c, 0);
     const void *d_buffer, *d_starts, *d_ends, *d_first;
     ORCD_TRY(stage_in(c, SLOT_IN_A, buffer, buffer_len, in_dev, &d_buffer));
-    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, starts.data(), starts.size() * sizeof(uint64_t), false, &d_starts));
-    ORCD_TRY(stage_in(c, SLOT_IN_C, ends.data(), ends.size() * sizeof(uint64_t), false, &d_ends));
-    ORCD_TRY(stage_in(c, SLOT_IN_D, first_seg.data(), first_seg.size() * sizeof(uint32_t), false, &d_first));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, plan.starts.data(), plan.starts.size() * sizeof(uint64_t), false, &d_starts));
+    ORCD_TRY(stage_in(c, SLOT_IN_C, plan.ends.data(), plan.ends.size() * sizeof(uint64_t), false, &d_ends));
+    ORCD_TRY(stage_in(c, SLOT_IN_D, plan.first_seg.data(), plan.first_seg.size() * sizeof(uint32_t), false, &d_first));
     int64_t *d_out = out;
     if (!out_dev) {
         void *p;
@@ -487,33 +532,83 @@ int orcd_rlev2_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_le
     Rlev2Table t;
     SegTable seg = {};
     const int rc = rlev2_table(c, (const uint8_t *)d_buffer, buffer_len, total_values, (const uint64_t *)d_starts,
-                               starts.size(), (flags & ORCD_SIGNED) ? 1 : 0, &t, false,
+                               plan.starts.size(), (flags & ORCD_SIGNED) ? 1 : 0, &t, false,
                                (const uint64_t *)d_ends, &seg);
     if (!seg.seg_local) return rc;  // failed before the scan: there is nothing to look at
-    // Decoded as one stream, the values of a slice land where they belong only if every slice
-    // before it holds exactly the values it was said to hold: compare the scan's value offsets at
-    // the slice starts with the prefix sums of num_values.
-    void *d_val_off;
-    ORCD_TRY(ensure(c, SLOT_TMP, first_seg.size() * sizeof(uint64_t), &d_val_off));
-    std::vector<uint64_t> got_off(first_seg.size());
-    HIP_TRY(c, launch_seg_value_offsets(c->stream, seg, (const uint32_t *)d_first, (uint32_t)first_seg.size(),
-                                        (uint64_t *)d_val_off));
-    HIP_TRY(c, hipMemcpyAsync(got_off.data(), d_val_off, got_off.size() * sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (size_t k = 0; k < got_off.size(); k++) {
-        if (got_off[k] != want_off[k]) {  // slice k - 1 is the first that is off
-            if (bad_slice) *bad_slice = slice_of[k ? k - 1 : 0];
-            return ORCD_OUT_OF_SPEC;
-        }
-    }
+    ORCD_TRY(verify_slice_offsets(c, seg, plan, (const uint32_t *)d_first, bad_slice));
     if (rc != ORCD_OK) {  // a run that does not parse, or too few values: in or after the last good start
-        if (bad_slice) *bad_slice = slice_of.back();
+        if (bad_slice) *bad_slice = plan.slice_of.back();
         return rc;
     }
     HIP_TRY(c, launch_rlev2_values(c->stream, t, d_out));
     mark(c, 3);
     if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, total_values * sizeof(int64_t)));
+    return ORCD_OK;
+}
+
+int orcd_boolean_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_len,
+                              const orcd_rlev2_slice *slices, size_t n_slices, uint8_t *out_bytes,
+                              uint64_t *set_bits, size_t *bad_slice, unsigned flags) {
+    if (bad_slice) *bad_slice = (size_t)-1;
+    if (!c || (buffer_len && !buffer) || (n_slices && !slices)) return ORCD_INVALID_ARGUMENT;
+    if (set_bits)
+        for (size_t i = 0; i < n_slices; i++) set_bits[i] = 0;
+    SegmentPlan plan;
+    ORCD_TRY(plan_segments(slices, n_slices, buffer_len, true, plan, bad_slice));
+    const uint64_t total_bytes = plan.total_units;  // decoded bytes, 8 values each
+    if (total_bytes == 0) return ORCD_OK;
+    if (!out_bytes) return ORCD_INVALID_ARGUMENT;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    mark(c, 0);
+    const void *d_buffer, *d_starts, *d_ends, *d_first;
+    ORCD_TRY(stage_in(c, SLOT_IN_A, buffer, buffer_len, in_dev, &d_buffer));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, plan.starts.data(), plan.starts.size() * sizeof(uint64_t), false, &d_starts));
+    ORCD_TRY(stage_in(c, SLOT_IN_C, plan.ends.data(), plan.ends.size() * sizeof(uint64_t), false, &d_ends));
+    ORCD_TRY(stage_in(c, SLOT_IN_D, plan.first_seg.data(), plan.first_seg.size() * sizeof(uint32_t), false, &d_first));
+    uint8_t *d_out = out_bytes;
+    if (!out_dev) {
+        void *p;
+        ORCD_TRY(ensure(c, SLOT_OUT_A, total_bytes * 8, &p));
+        d_out = (uint8_t *)p;
+    }
+    ByteRleTable t;
+    SegTable seg = {};
+    const int rc = byte_rle_table(c, (const uint8_t *)d_buffer, buffer_len, total_bytes, (const uint64_t *)d_starts,
+                                  plan.starts.size(), &t, (const uint64_t *)d_ends, &seg);
+    if (!seg.seg_local) return rc;
+    ORCD_TRY(verify_slice_offsets(c, seg, plan, (const uint32_t *)d_first, bad_slice));
+    if (rc != ORCD_OK) {
+        if (bad_slice) *bad_slice = plan.slice_of.back();
+        return rc;
+    }
+    // every slice fills whole bytes, so the values of slice i start at 8 * (bytes before it); the
+    // up to 7 values between two slices are padding
+    HIP_TRY(c, launch_bool_expand(c->stream, (const uint8_t *)d_buffer, buffer_len, t.runs, t.win_first,
+                                  t.n_win_slots, t.n_runs, total_bytes * 8, d_out, nullptr, nullptr));
+    mark(c, 3);
+    if (set_bits) {
+        // per slice: where its values start in the output and how many there are
+        std::vector<uint64_t> where(2 * plan.slice_of.size());
+        for (size_t k = 0; k < plan.slice_of.size(); k++) {
+            where[k] = plan.want_off[k] * 8;
+            where[plan.slice_of.size() + k] = slices[plan.slice_of[k]].num_values;
+        }
+        const void *d_where;
+        void *d_counts;
+        ORCD_TRY(stage_in(c, SLOT_IN_B, where.data(), where.size() * sizeof(uint64_t), false, &d_where));
+        ORCD_TRY(ensure(c, SLOT_TMP, plan.slice_of.size() * sizeof(uint64_t), &d_counts));
+        HIP_TRY(c, launch_count_nonzero_slices(c->stream, d_out, (const uint64_t *)d_where,
+                                               (const uint64_t *)d_where + plan.slice_of.size(),
+                                               (uint32_t)plan.slice_of.size(), (uint64_t *)d_counts));
+        std::vector<uint64_t> counts(plan.slice_of.size());
+        HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, counts.size() * sizeof(uint64_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (size_t k = 0; k < counts.size(); k++) set_bits[plan.slice_of[k]] = counts[k];
+    }
+    if (!out_dev) ORCD_TRY(copy_out(c, out_bytes, d_out, total_bytes * 8));
     return ORCD_OK;
 }
 
@@ -1160,18 +1255,72 @@ struct StripeJob {
 int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
                        const uint32_t *columns, size_t n_columns, unsigned flags, orcd_column_data *out,
                        std::vector<StripeJob> &jobs) {
-    // 1. column regions and validity
+    // 1. column regions, and validity: the PRESENT streams gathered into one buffer and decoded by
+    //    one set of launches when there are several
+    std::vector<uint8_t> blob;
+    std::vector<orcd_rlev2_slice> slices;
+    std::vector<size_t> owner;
     for (size_t i = 0; i < n_columns; i++) {
         if (columns[i] >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
         jobs[i].type_kind = orcd_file_type_kind(file, columns[i]);
         ORCD_TRY(orcd_read_stripe_column(file, stripe, footer, columns[i], &jobs[i].col));
-        ORCD_TRY(column_validity(c, file, jobs[i].col, jobs[i].p, &jobs[i].n_values));
+        const ColumnStreams cs{file, jobs[i].col};
+        const uint8_t *sb;
+        size_t sl;
+        const uint64_t *ent;
+        size_t n_ent;
+        ORCD_TRY(cs.get(ORCD_STREAM_PRESENT, &sb, &sl, &ent, &n_ent, false));
+        if (!sb || orcd_column_number_of_rows(jobs[i].col) == 0) continue;
+        orcd_rlev2_slice s;
+        s.offset = blob.size();
+        s.length = sl;
+        s.num_values = orcd_column_number_of_rows(jobs[i].col);
+        s.entry_points = ent;
+        s.n_entries = n_ent;
+        blob.insert(blob.end(), sb, sb + sl);
+        slices.push_back(s);
+        owner.push_back(i);
     }
+    std::vector<bool> have_validity(n_columns, false);
+    if (slices.size() > 1) {
+        uint64_t arena_bytes = 0;
+        for (const auto &s : slices) arena_bytes += 8 * ((s.num_values + 7) / 8);
+        void *arena = nullptr;
+        ORCD_TRY(dev_alloc(c, arena_bytes, &arena));
+        std::vector<uint64_t> counts(slices.size());
+        const int rc = orcd_boolean_decode_batch(c, blob.data(), blob.size(), slices.data(), slices.size(),
+                                                 (uint8_t *)arena, counts.data(), nullptr, ORCD_OUT_DEVICE);
+        if (rc == ORCD_OK) {
+            uint64_t pos = 0;
+            for (size_t k = 0; k < owner.size(); k++) {
+                StripeJob &j = jobs[owner[k]];
+                const uint64_t rows = slices[k].num_values;
+                int e = dev_alloc(c, rows, &j.p.validity);
+                if (e == ORCD_OK && hipMemcpyAsync(j.p.validity, (uint8_t *)arena + pos, rows,
+                                                   hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+                    e = ORCD_HIP_ERROR;
+                if (e != ORCD_OK) {
+                    (void)hipFree(arena);
+                    return e;
+                }
+                j.n_values = counts[k];
+                have_validity[owner[k]] = true;
+                pos += 8 * ((rows + 7) / 8);
+            }
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        } else if (rc != ORCD_OUT_OF_SPEC) {
+            (void)hipFree(arena);
+            return rc;
+        }  // a stream that is out of spec: the per-column decode below says which
+        (void)hipFree(arena);
+    }
+    for (size_t i = 0; i < n_columns; i++)
+        if (!have_validity[i]) ORCD_TRY(column_validity(c, file, jobs[i].col, jobs[i].p, &jobs[i].n_values));
+    blob.clear();
+    slices.clear();
+    owner.clear();
     // 2. the DATA streams of the integer columns, gathered into one buffer and decoded by one
     //    set of launches (a decode call costs the same ~50 microseconds whatever its size)
-    std::vector<uint8_t> blob;
-    std::vector<orcd_rlev2_slice> slices;
-    std::vector<size_t> owner;
     uint64_t total = 0;
     for (size_t i = 0; i < n_columns; i++) {
         if (!is_int_kind(jobs[i].type_kind) || jobs[i].n_values == 0) continue;

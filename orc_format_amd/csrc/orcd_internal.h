@@ -143,10 +143,14 @@ hipError_t launch_rlev2_offsets(hipStream_t st, const Rlev2Table &t, const uint6
                                 int64_t *offsets);
 
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                 const uint64_t *entries, uint32_t n_seg, const SegTable &t);
+                                 const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
+                                 const SegTable &t);
 hipError_t launch_byte_rle_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                const uint64_t *entries, uint32_t n_seg, const SegTable &t,
-                                ByteRun *runs, uint32_t *win_first, uint32_t n_win_slots);
+                                const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
+                                const SegTable &t, ByteRun *runs, uint32_t *win_first,
+                                uint32_t n_win_slots);
+hipError_t launch_count_nonzero_slices(hipStream_t st, const uint8_t *bytes, const uint64_t *start,
+                                       const uint64_t *count, uint32_t n_slices, uint64_t *out);
 // slots of win_first for a stream of total_bytes decoded bytes
 size_t byte_rle_window_slots(uint64_t total_bytes);
 hipError_t launch_byte_rle_expand(hipStream_t st, const uint8_t *stream, uint64_t len,

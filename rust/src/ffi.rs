@@ -68,6 +68,10 @@ extern "C" {
     pub fn orcd_rlev2_decode_batch(ctx: *mut orcd_ctx, buffer: *const u8, buffer_len: usize,
                                    slices: *const orcd_rlev2_slice, n_slices: usize, out: *mut i64,
                                    bad_slice: *mut usize, flags: c_uint) -> c_int;
+    pub fn orcd_boolean_decode_batch(ctx: *mut orcd_ctx, buffer: *const u8, buffer_len: usize,
+                                     slices: *const orcd_rlev2_slice, n_slices: usize,
+                                     out_bytes: *mut u8, set_bits: *mut u64, bad_slice: *mut usize,
+                                     flags: c_uint) -> c_int;
     pub fn orcd_scatter_valid(ctx: *mut orcd_ctx, validity: *const u8, num_rows: usize,
                               dense: *const c_void, num_values: usize, elem_size: usize,
                               out: *mut c_void, flags: c_uint) -> c_int;

@@ -110,3 +110,42 @@ def test_batch_on_device_pointers():
     ctx.rlev2_batch((blob.data_ptr(), blob.numel()), slices, True, out_ptr=out.data_ptr(), device=True)
     ctx.synchronize()
     assert torch.equal(out, expect)
+
+
+def test_boolean_batch_equals_per_stream(oracle):
+    from orc_format_amd import default_context
+    from orc_format_amd.error import OrcError
+    ctx = default_context()
+    rng = np.random.default_rng(50)
+    for case in range(10):
+        parts, slices, want = [], [], []
+        pos = 0
+        for _ in range(int(rng.integers(1, 12))):
+            junk = bytes(rng.integers(0, 256, size=int(rng.integers(0, 9)), dtype=np.uint8))
+            parts.append(junk)
+            pos += len(junk)
+            n_bits = int(rng.integers(0, 30000)) if rng.integers(0, 5) else 0
+            if n_bits == 0:
+                slices.append((pos, 0, 0, None))
+                want.append(np.zeros(0, dtype=bool))
+                continue
+            bits = rng.random(n_bits) < rng.choice([0.02, 0.5, 0.98])
+            stream = enc.byte_rle(np.packbits(bits).tobytes())
+            slices.append((pos, len(stream), n_bits, None))
+            want.append(bits)
+            parts.append(stream)
+            pos += len(stream)
+        blob = b"".join(parts) + b"\x00" * 3
+        got, counts = ctx.boolean_batch(blob, slices)
+        for g, w, cnt in zip(got, want, counts):
+            assert (g == w).all() and cnt == int(w.sum())
+    # a stream that holds a byte less than it should
+    live = [i for i, s_ in enumerate(slices) if s_[2] > 64]
+    if live:
+        k = live[0]
+        off, ln, nv, ent = slices[k]
+        bad = list(slices)
+        bad[k] = (off, ln, nv + 8, ent)
+        with pytest.raises(OrcError):
+            ctx.boolean_batch(blob, bad)
+        assert [int(x.sum()) for x in ctx.boolean_batch(blob, slices)[0]] == [int(w.sum()) for w in want]
