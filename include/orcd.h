@@ -51,7 +51,8 @@ enum {
     ORCD_OUT_DEVICE = 4u,  /* output pointers are device memory */
     ORCD_CHECK_UTF8 = 8u,  /* strings: validate each value (tests/it/deserialize.rs:116-118) */
     ORCD_SCATTER_CARRY = 16u, /* orcd_scatter_valid: null rows repeat the next value (offsets) */
-    ORCD_ROW_ALIGNED = 32u /* orcd_decode_column: one slot per row instead of per non-null row */
+    ORCD_ROW_ALIGNED = 32u, /* orcd_decode_column: one slot per row instead of per non-null row */
+    ORCD_ENTRIES_HOST = 64u /* with ORCD_IN_DEVICE: the entry points are host memory all the same */
 };
 
 /* ---- stream kinds (src/proto.rs:127-136) and column encodings (src/proto.rs:149-154) -------- */
@@ -116,7 +117,8 @@ int orcd_rlev2_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t n
  * Every slice is a whole stream: `length` bytes at `offset` of `buffer` that encode exactly
  * `num_values` values; all slices share the signedness given by ORCD_SIGNED.  `entry_points`
  * (always a HOST pointer, nullable) are offsets relative to the slice, as for orcd_rlev2_decode.
- * The values of slice i are written to out + (sum of num_values of the slices before i).
+ * Slices come in ascending order of `offset` and do not overlap (gaps between them are fine);
+ * anything else is ORCD_INVALID_ARGUMENT.  The values of slice i are written to out + (sum of num_values of the slices before i).
  * A slice that does not hold exactly its num_values values, or does not parse, yields
  * ORCD_OUT_OF_SPEC with *bad_slice (nullable) set to a slice at or before the first bad one;
  * decode the slices one by one to pin it down. */
@@ -259,6 +261,14 @@ int orcd_column_get_stream(const orcd_column *column, int kind, const uint8_t **
 /* Column::encoding() / dictionary_size() / number_of_rows() (src/read/column.rs:58-72). */
 int orcd_column_encoding(const orcd_column *column, int *kind, uint32_t *dictionary_size);
 uint64_t orcd_column_number_of_rows(const orcd_column *column);
+/* For readers that fetch a whole stripe at once (one read, one copy to the device) and decode its
+ * streams where they lie: a column handle without the column's bytes (orcd_column_get_stream then
+ * fails; encoding, row count and entry points work), the place of one of its streams as an offset
+ * from the start of the stripe, and a plain positioned read of file bytes. */
+int orcd_stripe_column_open(orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
+                            uint32_t column, orcd_column **out);
+int orcd_column_stream_range(const orcd_column *column, int kind, uint64_t *offset, uint64_t *len);
+int orcd_file_read_at(orcd_file *file, uint64_t offset, uint64_t len, uint8_t *dst);
 /* Run-header entry points for orcd_rlev2_decode / orcd_byte_rle_decode taken from the column's
  * ROW_INDEX stream (src/proto.rs:89-99), which the crate skips (src/read/mod.rs:136).  Reads the
  * index stream on first use.  Returns a borrowed array (possibly empty) of ascending stream

@@ -13,7 +13,7 @@ OK, OUT_OF_SPEC, INVALID_UTF8, INVALID_COLUMN, INVALID_KIND, DECODE_FLOAT, DECOM
     INVALID_PROTO = range(8)
 UNSUPPORTED, HIP_ERROR, INVALID_ARGUMENT = 100, 101, 102
 
-SIGNED, IN_DEVICE, OUT_DEVICE, CHECK_UTF8, SCATTER_CARRY, ROW_ALIGNED = 1, 2, 4, 8, 16, 32
+SIGNED, IN_DEVICE, OUT_DEVICE, CHECK_UTF8, SCATTER_CARRY, ROW_ALIGNED, ENTRIES_HOST = 1, 2, 4, 8, 16, 32, 64
 
 
 class OrcdRun(C.Structure):
@@ -86,6 +86,9 @@ SIGNATURES = {
     "orcd_column_encoding": (C.c_int, [P, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "orcd_column_number_of_rows": (C.c_uint64, [P]),
     "orcd_column_entry_points": (C.c_int, [P, P, C.c_int, C.POINTER(P), C.POINTER(SZ)]),
+    "orcd_stripe_column_open": (C.c_int, [P, SZ, P, C.c_uint32, C.POINTER(P)]),
+    "orcd_column_stream_range": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "orcd_file_read_at": (C.c_int, [P, C.c_uint64, C.c_uint64, P]),
     "orcd_scatter_valid": (C.c_int, [P, P, SZ, P, SZ, SZ, P, C.c_uint]),
     "orcd_decode_column": (C.c_int, [P, P, SZ, P, C.c_uint32, C.c_uint, C.POINTER(ColumnData)]),
     "orcd_column_data_free": (None, [C.POINTER(ColumnData)]),

@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "orcd_internal.h"
@@ -37,6 +39,7 @@ enum Slot {
     N_SLOTS
 };
 
+constexpr int N_READERS = 4;  // threads that read a stripe's bytes, each through a pinned chunk of its own
 constexpr int N_EVENTS = 5;  // start, after header count + scan, after emit, after values / offsets, after string bytes
 
 }  // namespace
@@ -51,6 +54,8 @@ struct orcd_ctx {
     size_t cap[N_SLOTS] = {};
     ScanTotals *h_totals = nullptr;  // pinned
     uint64_t *h_scalars = nullptr;   // pinned, 8 words
+    uint8_t *h_stage[N_READERS] = {};  // pinned chunks for whole-stripe reads, allocated on first use
+    hipEvent_t ev_stage[N_READERS] = {};
     hipError_t last_hip = hipSuccess;
 };
 
@@ -364,6 +369,10 @@ int orcd_ctx_destroy(orcd_ctx *c) {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    for (int i = 0; i < N_READERS; i++) {
+        if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
+        if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return ORCD_OK;
@@ -422,7 +431,8 @@ int orcd_rlev2_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num
     mark(c, 0);
     const void *d_stream, *d_entries;
     ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
-    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t), in_dev, &d_entries));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t),
+                      in_dev && !(flags & ORCD_ENTRIES_HOST), &d_entries));
     int64_t *d_out = out;
     if (!out_dev) {
         void *p;
@@ -452,11 +462,15 @@ struct SegmentPlan {
 
 int plan_segments(const orcd_rlev2_slice *slices, size_t n_slices, size_t buffer_len, bool bits,
                   SegmentPlan &plan, size_t *bad_slice) {
+    uint64_t prev_end = 0;
     for (size_t i = 0; i < n_slices; i++) {
         const orcd_rlev2_slice &sl = slices[i];
         if (sl.offset > buffer_len || sl.length > buffer_len - sl.offset || (sl.n_entries && !sl.entry_points))
             return ORCD_INVALID_ARGUMENT;
         if (sl.num_values == 0) continue;
+        // the value kernels address a window's runs relative to the first of them
+        if (sl.offset < prev_end) return ORCD_INVALID_ARGUMENT;
+        prev_end = sl.offset + sl.length;
         plan.first_seg.push_back((uint32_t)plan.starts.size());
         plan.want_off.push_back(plan.total_units);
         plan.slice_of.push_back(i);
@@ -625,7 +639,8 @@ int orcd_rlev2_runs(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_v
     mark(c, 0);
     const void *d_stream, *d_entries;
     ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
-    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t), in_dev, &d_entries));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t),
+                      in_dev && !(flags & ORCD_ENTRIES_HOST), &d_entries));
     Rlev2Table t;
     ORCD_TRY(rlev2_table(c, (const uint8_t *)d_stream, len, num_values, (const uint64_t *)d_entries,
                          n_entries, (flags & ORCD_SIGNED) ? 1 : 0, &t, true));
@@ -668,7 +683,8 @@ int orcd_byte_rle_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t 
     mark(c, 0);
     const void *d_stream, *d_entries;
     ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
-    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t), in_dev, &d_entries));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t),
+                      in_dev && !(flags & ORCD_ENTRIES_HOST), &d_entries));
     uint8_t *d_out = out;
     if (!out_dev) {
         void *p;
@@ -694,7 +710,8 @@ int orcd_boolean_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t n
     mark(c, 0);
     const void *d_stream, *d_entries;
     ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
-    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t), in_dev, &d_entries));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t),
+                      in_dev && !(flags & ORCD_ENTRIES_HOST), &d_entries));
     void *flagbuf;
     ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flagbuf));
     ByteRleTable t;
@@ -779,7 +796,7 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
         const void *d_len_stream, *d_entries;
         ORCD_TRY(stage_in(c, SLOT_IN_A, length_stream, length_len, in_dev, &d_len_stream));
         ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, length_entry_points, n_length_entries * sizeof(uint64_t),
-                          in_dev, &d_entries));
+                          in_dev && !(flags & ORCD_ENTRIES_HOST), &d_entries));
         const uint8_t *ls = (const uint8_t *)d_len_stream;
         Rlev2Table t;
         ORCD_TRY(rlev2_table(c, ls, length_len, num_values, (const uint64_t *)d_entries,
@@ -997,9 +1014,18 @@ enum TypeKind {  // proto Type.Kind (src/proto.rs:181-203)
     T_UNION = 13, T_DECIMAL = 14, T_DATE = 15, T_VARCHAR = 16, T_CHAR = 17
 };
 
+// The bytes [lo, hi) of a stripe (offsets from the stripe's start) held on the device.
+struct StripeBytes {
+    const uint8_t *d_base = nullptr;
+    uint64_t lo = 0, hi = 0;
+};
+
 struct ColumnStreams {
     orcd_file *file;
     orcd_column *col;
+    const StripeBytes *dev;  // null: streams are host memory owned by `col`
+    // flags for the stream decoders: where the stream lies; results stay on the device
+    unsigned io() const { return ORCD_OUT_DEVICE | (dev ? (ORCD_IN_DEVICE | ORCD_ENTRIES_HOST) : 0u); }
     // a stream's bytes (empty when absent) and its ROW_INDEX entry points
     int get(int kind, const uint8_t **bytes, size_t *len, const uint64_t **entries, size_t *n_entries,
             bool required) const {
@@ -1007,7 +1033,18 @@ struct ColumnStreams {
         *len = 0;
         *entries = nullptr;
         *n_entries = 0;
-        const int rc = orcd_column_get_stream(col, kind, bytes, len);
+        int rc;
+        if (dev) {
+            uint64_t off = 0, n = 0;
+            rc = orcd_column_stream_range(col, kind, &off, &n);
+            if (rc == ORCD_OK) {
+                if (off < dev->lo || off > dev->hi || n > dev->hi - off) return ORCD_OUT_OF_SPEC;
+                *bytes = dev->d_base + (off - dev->lo);
+                *len = (size_t)n;
+            }
+        } else {
+            rc = orcd_column_get_stream(col, kind, bytes, len);
+        }
         if (rc == ORCD_INVALID_KIND && !required) return ORCD_OK;
         if (rc != ORCD_OK) return rc;
         return orcd_column_entry_points(file, col, kind, entries, n_entries);
@@ -1058,8 +1095,8 @@ struct Pending {
 
 // validity (deserialize_validity, deserialize.rs:13-25): p.validity[rows] on the device and the
 // number of non-null rows
-int column_validity(orcd_ctx *c, orcd_file *file, orcd_column *col, Pending &p, uint64_t *n_values) {
-    const ColumnStreams cs{file, col};
+int column_validity(orcd_ctx *c, const ColumnStreams &cs, Pending &p, uint64_t *n_values) {
+    orcd_column *col = cs.col;
     const uint64_t rows = orcd_column_number_of_rows(col);
     const uint8_t *sb;
     size_t sl;
@@ -1070,7 +1107,7 @@ int column_validity(orcd_ctx *c, orcd_file *file, orcd_column *col, Pending &p, 
     ORCD_TRY(cs.get(ORCD_STREAM_PRESENT, &sb, &sl, &ent, &n_ent, false));
     if (sb) {
         ORCD_TRY(orcd_boolean_decode(c, sb, sl, rows, ent, n_ent, (uint8_t *)p.validity, nullptr, n_values,
-                                     ORCD_OUT_DEVICE));
+                                     cs.io()));
     } else {
         HIP_TRY(c, hipMemsetAsync(p.validity, 1, rows, c->stream));
     }
@@ -1081,11 +1118,11 @@ bool is_int_kind(int k) { return k == T_SHORT || k == T_INT || k == T_LONG || k 
 
 // The values of a column whose validity is in p.  `ints_done`: p.values already holds the dense
 // values of an integer column (decoded in a batch with other columns).
-int column_values(orcd_ctx *c, orcd_file *file, orcd_column *col, int type_kind, unsigned flags,
+int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned flags,
                   Pending &p, uint64_t n_values, bool ints_done, orcd_column_data *out) {
     const bool out_dev = flags & ORCD_OUT_DEVICE, row_aligned = flags & ORCD_ROW_ALIGNED;
-    const unsigned io = ORCD_OUT_DEVICE;  // streams are host memory, results stay on the device
-    const ColumnStreams cs{file, col};
+    const unsigned io = cs.io();
+    orcd_column *col = cs.col;
     const uint64_t rows = orcd_column_number_of_rows(col);
     const uint8_t *sb;
     size_t sl;
@@ -1239,8 +1276,9 @@ int decode_column_impl(orcd_ctx *c, orcd_file *file, orcd_column *col, int type_
                        orcd_column_data *out) {
     Pending p;
     uint64_t n_values = 0;
-    ORCD_TRY(column_validity(c, file, col, p, &n_values));
-    return column_values(c, file, col, type_kind, flags, p, n_values, false, out);
+    const ColumnStreams cs{file, col, nullptr};
+    ORCD_TRY(column_validity(c, cs, p, &n_values));
+    return column_values(c, cs, type_kind, flags, p, n_values, false, out);
 }
 
 // Columns of a stripe under construction.
@@ -1248,130 +1286,225 @@ struct StripeJob {
     orcd_column *col = nullptr;
     int type_kind = 0;
     uint64_t n_values = 0;
-    bool batched = false;
+    bool have_validity = false, batched = false;
     Pending p;
+};
+
+constexpr size_t STAGE_CHUNK = 8u << 20;
+// Streams up to this size share one set of launches with their peers; a larger one gains nothing
+// from it (a decode call costs ~50 microseconds whatever its size) and is decoded where it lies.
+constexpr uint64_t BATCH_STREAM_MAX = 4u << 20;
+
+// File bytes [file_off, file_off + len) -> d_dst.  A single thread reading from the page cache
+// moves a few GB/s, far less than the host-to-device link: N_READERS threads take the chunks in
+// turn, each reading into a pinned chunk of its own and queueing that chunk's copy, so reads
+// overlap each other and the copies.
+int load_region(orcd_ctx *c, orcd_file *file, uint64_t file_off, uint64_t len, uint8_t *d_dst) {
+    for (int i = 0; i < N_READERS; i++) {
+        if (!c->h_stage[i]) HIP_TRY(c, hipHostMalloc((void **)&c->h_stage[i], STAGE_CHUNK, hipHostMallocDefault));
+        if (!c->ev_stage[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+    }
+    const uint64_t n_chunks = (len + STAGE_CHUNK - 1) / STAGE_CHUNK;
+    const int n_threads = (int)std::min<uint64_t>(N_READERS, n_chunks);
+    std::atomic<int> status{ORCD_OK};
+    std::atomic<int> hip_status{(int)hipSuccess};
+    auto reader = [&](int t) {
+        if (hipSetDevice(c->device) != hipSuccess) {
+            status = ORCD_HIP_ERROR;
+            return;
+        }
+        bool used = false;
+        for (uint64_t k = (uint64_t)t; k < n_chunks && status == ORCD_OK; k += (uint64_t)n_threads) {
+            const uint64_t pos = k * STAGE_CHUNK, n = std::min<uint64_t>(STAGE_CHUNK, len - pos);
+            hipError_t e = used ? hipEventSynchronize(c->ev_stage[t]) : hipSuccess;  // the chunk's last copy is done
+            if (e == hipSuccess) {
+                const int rc = orcd_file_read_at(file, file_off + pos, n, c->h_stage[t]);
+                if (rc != ORCD_OK) {
+                    status = rc;
+                    return;
+                }
+                e = hipMemcpyAsync(d_dst + pos, c->h_stage[t], n, hipMemcpyHostToDevice, c->stream);
+            }
+            if (e == hipSuccess) e = hipEventRecord(c->ev_stage[t], c->stream);
+            if (e != hipSuccess) {
+                hip_status = (int)e;
+                status = ORCD_HIP_ERROR;
+                return;
+            }
+            used = true;
+        }
+    };
+    if (n_threads <= 1) {
+        if (n_threads == 1) reader(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads; t++) pool.emplace_back(reader, t);
+        reader(0);
+        for (auto &th : pool) th.join();
+    }
+    if (status != ORCD_OK) {
+        if (hip_status != (int)hipSuccess) c->last_hip = (hipError_t)hip_status.load();
+        (void)hipStreamSynchronize(c->stream);  // queued copies still read the pinned chunks
+        return status;
+    }
+    return ORCD_OK;
+}
+
+// One batch of streams that lie in the stripe's device copy: slice offsets are relative to the
+// first byte any of them uses.
+struct StreamBatch {
+    std::vector<orcd_rlev2_slice> slices;
+    std::vector<size_t> owner;
+    uint64_t lo = ~0ull, hi = 0;
+    void add(size_t job, const uint8_t *d_bytes, size_t len, uint64_t units, const uint64_t *ent, size_t n_ent) {
+        orcd_rlev2_slice s;
+        s.offset = (uint64_t)(uintptr_t)d_bytes;  // absolute for now, rebased by finish()
+        s.length = len;
+        s.num_values = units;
+        s.entry_points = ent;
+        s.n_entries = n_ent;
+        lo = std::min<uint64_t>(lo, s.offset);
+        hi = std::max<uint64_t>(hi, s.offset + len);
+        slices.push_back(s);
+        owner.push_back(job);
+    }
+    // slices in the order they lie in memory (the batch calls want that), offsets from the first
+    const uint8_t *finish() {
+        std::vector<size_t> order(slices.size());
+        for (size_t k = 0; k < order.size(); k++) order[k] = k;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return slices[a].offset < slices[b].offset; });
+        std::vector<orcd_rlev2_slice> s2;
+        std::vector<size_t> o2;
+        for (size_t k : order) {
+            s2.push_back(slices[k]);
+            s2.back().offset -= lo;
+            o2.push_back(owner[k]);
+        }
+        slices.swap(s2);
+        owner.swap(o2);
+        return (const uint8_t *)(uintptr_t)lo;
+    }
 };
 
 int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
                        const uint32_t *columns, size_t n_columns, unsigned flags, orcd_column_data *out,
-                       std::vector<StripeJob> &jobs) {
-    // 1. column regions, and validity: the PRESENT streams gathered into one buffer and decoded by
-    //    one set of launches when there are several
-    std::vector<uint8_t> blob;
-    std::vector<orcd_rlev2_slice> slices;
-    std::vector<size_t> owner;
+                       std::vector<StripeJob> &jobs, Pending &stripe_mem) {
+    // 1. the bytes the columns' streams span, read once and copied once to the device
+    orcd_stripe_info si;
+    ORCD_TRY(orcd_file_stripe(file, stripe, &si));
+    std::vector<bool> wanted(orcd_file_num_types(file), false);
     for (size_t i = 0; i < n_columns; i++) {
-        if (columns[i] >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
+        if (columns[i] >= wanted.size()) return ORCD_INVALID_COLUMN;
+        wanted[columns[i]] = true;
         jobs[i].type_kind = orcd_file_type_kind(file, columns[i]);
-        ORCD_TRY(orcd_read_stripe_column(file, stripe, footer, columns[i], &jobs[i].col));
-        const ColumnStreams cs{file, jobs[i].col};
-        const uint8_t *sb;
-        size_t sl;
-        const uint64_t *ent;
-        size_t n_ent;
-        ORCD_TRY(cs.get(ORCD_STREAM_PRESENT, &sb, &sl, &ent, &n_ent, false));
-        if (!sb || orcd_column_number_of_rows(jobs[i].col) == 0) continue;
-        orcd_rlev2_slice s;
-        s.offset = blob.size();
-        s.length = sl;
-        s.num_values = orcd_column_number_of_rows(jobs[i].col);
-        s.entry_points = ent;
-        s.n_entries = n_ent;
-        blob.insert(blob.end(), sb, sb + sl);
-        slices.push_back(s);
-        owner.push_back(i);
+        ORCD_TRY(orcd_stripe_column_open(file, stripe, footer, columns[i], &jobs[i].col));
     }
-    std::vector<bool> have_validity(n_columns, false);
-    if (slices.size() > 1) {
+    StripeBytes sb;
+    sb.lo = ~0ull;
+    const size_t n_streams = orcd_stripe_footer_num_streams(footer);
+    for (size_t k = 0; k < n_streams; k++) {
+        orcd_stream_info info;
+        ORCD_TRY(orcd_stripe_footer_stream(footer, k, &info));
+        if (info.kind == ORCD_STREAM_ROW_INDEX || info.column >= wanted.size() || !wanted[info.column]) continue;
+        if (info.offset + info.length < info.offset) return ORCD_OUT_OF_SPEC;
+        sb.lo = std::min(sb.lo, info.offset);
+        sb.hi = std::max(sb.hi, info.offset + info.length);
+    }
+    if (sb.lo > sb.hi) sb.lo = sb.hi = 0;
+    ORCD_TRY(dev_alloc(c, sb.hi - sb.lo, &stripe_mem.tmp));
+    sb.d_base = (const uint8_t *)stripe_mem.tmp;
+    ORCD_TRY(load_region(c, file, si.offset + sb.lo, sb.hi - sb.lo, (uint8_t *)stripe_mem.tmp));
+
+    // 2. validity: the small PRESENT streams in one set of launches
+    {
+        StreamBatch batch;
         uint64_t arena_bytes = 0;
-        for (const auto &s : slices) arena_bytes += 8 * ((s.num_values + 7) / 8);
-        void *arena = nullptr;
-        ORCD_TRY(dev_alloc(c, arena_bytes, &arena));
-        std::vector<uint64_t> counts(slices.size());
-        const int rc = orcd_boolean_decode_batch(c, blob.data(), blob.size(), slices.data(), slices.size(),
-                                                 (uint8_t *)arena, counts.data(), nullptr, ORCD_OUT_DEVICE);
-        if (rc == ORCD_OK) {
-            uint64_t pos = 0;
-            for (size_t k = 0; k < owner.size(); k++) {
-                StripeJob &j = jobs[owner[k]];
-                const uint64_t rows = slices[k].num_values;
-                int e = dev_alloc(c, rows, &j.p.validity);
-                if (e == ORCD_OK && hipMemcpyAsync(j.p.validity, (uint8_t *)arena + pos, rows,
-                                                   hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
-                    e = ORCD_HIP_ERROR;
-                if (e != ORCD_OK) {
-                    (void)hipFree(arena);
-                    return e;
+        for (size_t i = 0; i < n_columns; i++) {
+            const ColumnStreams cs{file, jobs[i].col, &sb};
+            const uint64_t rows = orcd_column_number_of_rows(jobs[i].col);
+            const uint8_t *b;
+            size_t l, n_ent;
+            const uint64_t *ent;
+            ORCD_TRY(cs.get(ORCD_STREAM_PRESENT, &b, &l, &ent, &n_ent, false));
+            if (!b || rows == 0 || l > BATCH_STREAM_MAX) continue;
+            batch.add(i, b, l, rows, ent, n_ent);
+            arena_bytes += 8 * ((rows + 7) / 8);
+        }
+        if (batch.slices.size() > 1) {
+            const uint8_t *d_first = batch.finish();
+            ORCD_TRY(dev_alloc(c, arena_bytes, &stripe_mem.tmp2));
+            std::vector<uint64_t> counts(batch.slices.size());
+            const int rc = orcd_boolean_decode_batch(c, d_first, batch.hi - batch.lo, batch.slices.data(),
+                                                     batch.slices.size(), (uint8_t *)stripe_mem.tmp2,
+                                                     counts.data(), nullptr, ORCD_IN_DEVICE | ORCD_OUT_DEVICE);
+            if (rc == ORCD_OK) {
+                uint64_t pos = 0;
+                for (size_t k = 0; k < batch.owner.size(); k++) {
+                    StripeJob &j = jobs[batch.owner[k]];
+                    const uint64_t rows = batch.slices[k].num_values;
+                    ORCD_TRY(dev_alloc(c, rows, &j.p.validity));
+                    HIP_TRY(c, hipMemcpyAsync(j.p.validity, (uint8_t *)stripe_mem.tmp2 + pos, rows,
+                                              hipMemcpyDeviceToDevice, c->stream));
+                    j.n_values = counts[k];
+                    j.have_validity = true;
+                    pos += 8 * ((rows + 7) / 8);
                 }
-                j.n_values = counts[k];
-                have_validity[owner[k]] = true;
-                pos += 8 * ((rows + 7) / 8);
-            }
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-        } else if (rc != ORCD_OUT_OF_SPEC) {
-            (void)hipFree(arena);
-            return rc;
-        }  // a stream that is out of spec: the per-column decode below says which
-        (void)hipFree(arena);
+            } else if (rc != ORCD_OUT_OF_SPEC) {
+                return rc;
+            }  // a stream that is out of spec: the per-column decode below says which
+        }
     }
-    for (size_t i = 0; i < n_columns; i++)
-        if (!have_validity[i]) ORCD_TRY(column_validity(c, file, jobs[i].col, jobs[i].p, &jobs[i].n_values));
-    blob.clear();
-    slices.clear();
-    owner.clear();
-    // 2. the DATA streams of the integer columns, gathered into one buffer and decoded by one
-    //    set of launches (a decode call costs the same ~50 microseconds whatever its size)
-    uint64_t total = 0;
     for (size_t i = 0; i < n_columns; i++) {
-        if (!is_int_kind(jobs[i].type_kind) || jobs[i].n_values == 0) continue;
-        const ColumnStreams cs{file, jobs[i].col};
-        const uint8_t *sb;
-        size_t sl;
-        const uint64_t *ent;
-        size_t n_ent;
-        if (cs.get(ORCD_STREAM_DATA, &sb, &sl, &ent, &n_ent, true) != ORCD_OK) continue;  // reported per column below
-        orcd_rlev2_slice s;
-        s.offset = blob.size();
-        s.length = sl;
-        s.num_values = jobs[i].n_values;
-        s.entry_points = ent;
-        s.n_entries = n_ent;
-        blob.insert(blob.end(), sb, sb + sl);
-        slices.push_back(s);
-        owner.push_back(i);
-        total += jobs[i].n_values;
+        if (jobs[i].have_validity) continue;
+        const ColumnStreams cs{file, jobs[i].col, &sb};
+        ORCD_TRY(column_validity(c, cs, jobs[i].p, &jobs[i].n_values));
     }
-    if (slices.size() > 1) {
-        void *arena = nullptr;
-        ORCD_TRY(dev_alloc(c, total * 8, &arena));
-        const int rc = orcd_rlev2_decode_batch(c, blob.data(), blob.size(), slices.data(), slices.size(),
-                                               (int64_t *)arena, nullptr, ORCD_SIGNED | ORCD_OUT_DEVICE);
-        if (rc == ORCD_OK) {
-            uint64_t pos = 0;
-            for (size_t k = 0; k < owner.size(); k++) {
-                StripeJob &j = jobs[owner[k]];
-                int e = dev_alloc(c, j.n_values * 8, &j.p.values);
-                if (e == ORCD_OK && hipMemcpyAsync(j.p.values, (int64_t *)arena + pos, j.n_values * 8,
-                                                   hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
-                    e = ORCD_HIP_ERROR;
-                if (e != ORCD_OK) {
-                    (void)hipFree(arena);
-                    return e;
+    // 3. the small DATA streams of the integer columns in one set of launches
+    {
+        StreamBatch batch;
+        uint64_t total = 0;
+        for (size_t i = 0; i < n_columns; i++) {
+            if (!is_int_kind(jobs[i].type_kind) || jobs[i].n_values == 0) continue;
+            const ColumnStreams cs{file, jobs[i].col, &sb};
+            const uint8_t *b;
+            size_t l, n_ent;
+            const uint64_t *ent;
+            if (cs.get(ORCD_STREAM_DATA, &b, &l, &ent, &n_ent, true) != ORCD_OK) continue;  // reported per column below
+            if (l > BATCH_STREAM_MAX) continue;
+            batch.add(i, b, l, jobs[i].n_values, ent, n_ent);
+            total += jobs[i].n_values;
+        }
+        if (batch.slices.size() > 1) {
+            const uint8_t *d_first = batch.finish();
+            void *arena = nullptr;  // (the validity arena may still feed copies on the stream)
+            ORCD_TRY(dev_alloc(c, total * 8, &arena));
+            Pending hold;
+            hold.tmp = arena;
+            const int rc = orcd_rlev2_decode_batch(c, d_first, batch.hi - batch.lo, batch.slices.data(),
+                                                   batch.slices.size(), (int64_t *)arena, nullptr,
+                                                   ORCD_SIGNED | ORCD_IN_DEVICE | ORCD_OUT_DEVICE);
+            if (rc == ORCD_OK) {
+                uint64_t pos = 0;
+                for (size_t k = 0; k < batch.owner.size(); k++) {
+                    StripeJob &j = jobs[batch.owner[k]];
+                    ORCD_TRY(dev_alloc(c, j.n_values * 8, &j.p.values));
+                    HIP_TRY(c, hipMemcpyAsync(j.p.values, (int64_t *)arena + pos, j.n_values * 8,
+                                              hipMemcpyDeviceToDevice, c->stream));
+                    j.batched = true;
+                    pos += j.n_values;
                 }
-                j.batched = true;
-                pos += j.n_values;
+                HIP_TRY(c, hipStreamSynchronize(c->stream));  // `arena` is released at scope exit
+            } else if (rc != ORCD_OUT_OF_SPEC) {
+                return rc;
             }
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-        } else if (rc != ORCD_OUT_OF_SPEC) {
-            (void)hipFree(arena);
-            return rc;
-        }  // a stream that is out of spec: the per-column decode below says which
-        (void)hipFree(arena);
+        }
     }
-    // 3. everything else, column by column
-    for (size_t i = 0; i < n_columns; i++)
-        ORCD_TRY(column_values(c, file, jobs[i].col, jobs[i].type_kind, flags, jobs[i].p, jobs[i].n_values,
-                               jobs[i].batched, &out[i]));
+    // 4. everything else, column by column
+    for (size_t i = 0; i < n_columns; i++) {
+        const ColumnStreams cs{file, jobs[i].col, &sb};
+        ORCD_TRY(column_values(c, cs, jobs[i].type_kind, flags, jobs[i].p, jobs[i].n_values, jobs[i].batched,
+                               &out[i]));
+    }
     return ORCD_OK;
 }
 
@@ -1384,8 +1517,9 @@ int orcd_decode_stripe(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     if (orcd_file_compression(file) != 0) return ORCD_UNSUPPORTED;  // chunk framing is not decoded here
     DeviceGuard g(c->device);
     std::vector<StripeJob> jobs(n_columns);
-    const int rc = decode_stripe_impl(c, file, stripe, footer, columns, n_columns, flags, out, jobs);
-    (void)hipStreamSynchronize(c->stream);  // the columns' bytes were read by asynchronous copies
+    Pending stripe_mem;  // the stripe's bytes on the device, and the validity arena
+    const int rc = decode_stripe_impl(c, file, stripe, footer, columns, n_columns, flags, out, jobs, stripe_mem);
+    (void)hipStreamSynchronize(c->stream);  // before the device buffers of this call are released
     for (auto &j : jobs)
         if (j.col) orcd_column_free(j.col);
     if (rc != ORCD_OK)

@@ -4,6 +4,7 @@
 // (src/read/mod.rs:46-159, src/read/column.rs:11-79) with a hand-written reader for the handful of
 // protobuf messages involved (src/proto.rs:89-99, 113-164, 166-217, 236-278).  No GPU code here.
 #include <stdio.h>
+#include <unistd.h>
 #include <string.h>
 
 #include <algorithm>
@@ -96,13 +97,25 @@ struct Source {
     bool read_at(uint64_t off, uint64_t n, std::vector<uint8_t> &out) const {
         if (off > len || n > len - off) return false;
         out.resize(n);
+        return read_into(off, n, out.data());
+    }
+    bool read_into(uint64_t off, uint64_t n, uint8_t *dst) const {
+        if (off > len || n > len - off) return false;
         if (n == 0) return true;
         if (mem) {
-            memcpy(out.data(), mem + off, n);
+            memcpy(dst, mem + off, n);
             return true;
         }
-        if (fseeko(f, (off_t)off, SEEK_SET) != 0) return false;
-        return fread(out.data(), 1, n, f) == n;
+        // positioned reads on the descriptor: safe from several threads at once
+        const int fd = fileno(f);
+        while (n) {
+            const ssize_t got = pread(fd, dst, n, (off_t)off);
+            if (got <= 0) return false;
+            dst += got;
+            off += (uint64_t)got;
+            n -= (uint64_t)got;
+        }
+        return true;
     }
 };
 
@@ -124,6 +137,7 @@ struct orcd_stripe_footer {
 };
 
 struct orcd_column {
+    bool has_data = true;       // false: a handle without the column's bytes (orcd_stripe_column_open)
     std::vector<uint8_t> data;  // all non-ROW_INDEX streams of the column, in file order
     uint32_t column = 0;
     uint64_t number_of_rows = 0;
@@ -457,8 +471,42 @@ int orcd_read_stripe_column(orcd_file *f, size_t stripe, const orcd_stripe_foote
 
 void orcd_column_free(orcd_column *col) { delete col; }
 
+int orcd_stripe_column_open(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft, uint32_t column,
+                            orcd_column **out) {
+    if (!f || !ft || !out) return ORCD_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (stripe >= f->stripes.size()) return ORCD_INVALID_ARGUMENT;
+    bool found = false;
+    for (const auto &s : ft->streams) found = found || (s.column == column && s.kind != ORCD_STREAM_ROW_INDEX);
+    if (!found) return ORCD_INVALID_COLUMN;
+    orcd_column *col = new orcd_column();
+    col->has_data = false;
+    col->column = column;
+    col->number_of_rows = f->stripes[stripe].number_of_rows;
+    col->stripe = stripe;
+    col->footer = ft;
+    *out = col;
+    return ORCD_OK;
+}
+
+int orcd_column_stream_range(const orcd_column *col, int kind, uint64_t *offset, uint64_t *len) {
+    if (!col || !offset || !len) return ORCD_INVALID_ARGUMENT;
+    for (const auto &s : col->footer->streams) {
+        if (s.column != col->column || (int)s.kind != kind || s.kind == ORCD_STREAM_ROW_INDEX) continue;
+        *offset = s.offset;
+        *len = s.length;
+        return ORCD_OK;
+    }
+    return ORCD_INVALID_KIND;
+}
+
+int orcd_file_read_at(orcd_file *f, uint64_t offset, uint64_t len, uint8_t *dst) {
+    if (!f || (len && !dst)) return ORCD_INVALID_ARGUMENT;
+    return f->src.read_into(offset, len, dst) ? ORCD_OK : ORCD_OUT_OF_SPEC;
+}
+
 int orcd_column_get_stream(const orcd_column *col, int kind, const uint8_t **bytes, size_t *len) {
-    if (!col || !bytes || !len) return ORCD_INVALID_ARGUMENT;
+    if (!col || !bytes || !len || !col->has_data) return ORCD_INVALID_ARGUMENT;
     // running offset over the column's non-ROW_INDEX streams (src/read/column.rs:38-55)
     uint64_t start = 0;
     for (const auto &s : col->footer->streams) {

@@ -54,6 +54,22 @@ def test_batch_equals_per_stream(oracle, signed, with_entries):
             pos += nv
 
 
+def test_batch_refuses_slices_out_of_order():
+    """Slices are given in the order they lie in the buffer, without overlap."""
+    from orc_format_amd import default_context
+    from orc_format_amd.error import OrcError
+    ctx = default_context()
+    rng = np.random.default_rng(45)
+    blob, slices, expect = _blob(rng, 6, True, False)
+    live = [s for s in slices if s[2]]
+    assert len(live) >= 2
+    assert (ctx.rlev2_batch(blob, live, True) == expect).all()
+    for bad in (live[::-1], [live[0], live[0]]):
+        with pytest.raises(OrcError) as ei:
+            ctx.rlev2_batch(blob, bad, True)
+        assert ei.value.code == 102
+
+
 def test_batch_refuses_wrong_counts_and_damage(oracle):
     from orc_format_amd import default_context
     from orc_format_amd.error import OrcError

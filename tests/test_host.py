@@ -68,6 +68,42 @@ def test_metadata_matches_python_parse(golden_dir, name):
                     assert bytes(column.get_stream(kind)) == expect
 
 
+@pytest.mark.parametrize("name", ["test.orc", "string_dict.orc"])
+def test_stream_ranges_without_column_bytes(golden_dir, name):
+    """A column handle opened without its bytes gives every stream's place in the stripe, and a
+    positioned read of that place returns what the column region holds."""
+    import ctypes as C
+    lib = N.lib()
+    path = os.path.join(golden_dir, name)
+    ref = op.OrcFile(path)
+    md = read.read_metadata(path)
+    for si in range(len(ref.stripes)):
+        footer = read.read_stripe_footer(md, si)
+        for col in range(1, len(ref.types)):
+            handle = C.c_void_p()
+            assert lib.orcd_stripe_column_open(md._h, si, footer._h, col, C.byref(handle)) == 0
+            try:
+                b, n = C.c_void_p(), C.c_size_t()
+                assert lib.orcd_column_get_stream(handle, int(StreamKind.Data), C.byref(b), C.byref(n)) == 102
+                assert lib.orcd_column_number_of_rows(handle) == ref.stripes[si].number_of_rows
+                for kind in (StreamKind.Present, StreamKind.Data, StreamKind.Length, StreamKind.DictionaryData):
+                    off, ln = C.c_uint64(), C.c_uint64()
+                    rc = lib.orcd_column_stream_range(handle, int(kind), C.byref(off), C.byref(ln))
+                    expect = ref.stream(si, col, int(kind))
+                    if expect is None:
+                        assert rc == 4
+                        continue
+                    assert rc == 0 and ln.value == len(expect)
+                    buf = (C.c_uint8 * max(1, ln.value))()
+                    assert lib.orcd_file_read_at(md._h, ref.stripes[si].offset + off.value, ln.value, buf) == 0
+                    assert bytes(buf[:ln.value]) == expect
+            finally:
+                lib.orcd_column_free(handle)
+    size = os.path.getsize(path)
+    assert lib.orcd_file_read_at(md._h, size - 1, 2, (C.c_uint8 * 2)()) == 1
+    assert lib.orcd_stripe_column_open(md._h, 0, footer._h, 99, C.byref(C.c_void_p())) == 3
+
+
 def test_memory_image_and_dictionary_size(golden_dir):
     with open(os.path.join(golden_dir, "string_dict.orc"), "rb") as f:
         image = f.read()
