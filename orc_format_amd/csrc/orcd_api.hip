@@ -36,6 +36,7 @@ enum Slot {
     SLOT_SCAN_SUMS,
     SLOT_FLAGS,
     SLOT_TMP,
+    SLOT_STAGED_RUNS,
     N_SLOTS
 };
 
@@ -209,9 +210,14 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
     const uint64_t *seg_ends = n_entries ? d_seg_ends : nullptr;
+    // With more than a few segments the counting pass keeps the descriptors it parses, and the
+    // run table is then written without a second walk of the header chain.
+    void *staged = nullptr;
+    if (n_seg >= 64) ORCD_TRY(ensure(c, SLOT_STAGED_RUNS, (size_t)n_seg * STAGED_RUNS * sizeof(uint64_t), &staged));
     ScanResult sr;
     ORCD_TRY(count_and_scan(c, n_seg, num_values, [&](const SegTable &st) {
-        return launch_rlev2_count(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, st);
+        return launch_rlev2_count(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, st,
+                                  (uint64_t *)staged);
     }, &sr));
     mark(c, 1);
     if (seg_table) *seg_table = sr.table;
@@ -223,9 +229,15 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
     ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(uint64_t), &runs));
     ORCD_TRY(ensure(c, SLOT_GROUPS, (size_t)n_slots * sizeof(uint32_t), &groups));
     ORCD_TRY(ensure(c, SLOT_GROUP_RUNS, (size_t)n_slots * sizeof(RunEntry), &group_runs));
-    HIP_TRY(c, launch_rlev2_emit(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, sr.table,
-                                 (uint64_t *)runs, (uint32_t *)groups, (RunEntry *)group_runs,
-                                 (uint32_t)n_slots, full_table));
+    if (staged)
+        HIP_TRY(c, launch_rlev2_emit_staged(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed,
+                                            sr.table, (const uint64_t *)staged, (uint64_t *)runs,
+                                            (uint32_t *)groups, (RunEntry *)group_runs, (uint32_t)n_slots,
+                                            full_table));
+    if (!staged || sr.totals.max_seg_runs > STAGED_RUNS)
+        HIP_TRY(c, launch_rlev2_emit(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, sr.table,
+                                     (uint64_t *)runs, (uint32_t *)groups, (RunEntry *)group_runs,
+                                     (uint32_t)n_slots, full_table, staged ? STAGED_RUNS : 0));
     mark(c, 2);
     const uint64_t covered = std::min<uint64_t>(num_values, sr.totals.total_vals);
     t->stream = d_stream;

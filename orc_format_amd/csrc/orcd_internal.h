@@ -79,7 +79,8 @@ struct ScanTotals {
     uint64_t total_runs;
     uint32_t error;      // ORCD_* status; 0 when the first `num_values` values are decodable
     uint32_t error_seg;
-    uint64_t pad;
+    uint32_t max_seg_runs;  // most runs any one segment holds
+    uint32_t pad;
 };
 
 constexpr uint32_t SEG_OK = 0;
@@ -104,13 +105,24 @@ struct SegTable;  // seg_scan.h
 
 // entries: start offset of every segment; seg_ends (nullable): its end, when the segments are
 // slices of a larger buffer rather than one gapless stream.
+// The counting pass keeps the descriptors of a segment's first STAGED_RUNS runs in
+// staged[seg * STAGED_RUNS + k] (nullable): segments that hold no more than that are then emitted
+// by launch_rlev2_emit_staged, one lane per run, without walking the header chain a second time;
+// launch_rlev2_emit walks the segments with more than `staged_up_to` runs (0: all of them).
+constexpr uint32_t STAGED_RUNS = 64;
 hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                               const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
-                              int is_signed, const SegTable &t);
+                              int is_signed, const SegTable &t, uint64_t *staged);
 hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                              const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                              int is_signed, const SegTable &t, uint64_t *runs, uint32_t *group_first,
-                             RunEntry *group_run, uint32_t n_group_slots, bool full_table);
+                             RunEntry *group_run, uint32_t n_group_slots, bool full_table,
+                             uint32_t staged_up_to);
+hipError_t launch_rlev2_emit_staged(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                    const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
+                                    int is_signed, const SegTable &t, const uint64_t *staged,
+                                    uint64_t *runs, uint32_t *group_first, RunEntry *group_run,
+                                    uint32_t n_group_slots, bool full_table);
 // Parallel check of a guessed header chain (see rlev2.hip): the size of the run at `pos`, and the
 // first k < n for which p + k * stride is not the header of a run of `stride` bytes (*first_fail
 // must hold n or more beforehand).

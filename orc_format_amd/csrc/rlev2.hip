@@ -15,6 +15,8 @@ namespace orcd {
 // small device helpers
 // ---------------------------------------------------------------------------------------------
 
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ uint32_t width_from_code(uint32_t code) {
     // ORC v1 "5 bit width encoding table": 0..23 -> 1..24, then 26 28 30 32 40 48 56 64
     if (code <= 23) return code + 1;
@@ -191,7 +193,11 @@ __device__ __forceinline__ Window16 buffered_window(const uint8_t *s, uint64_t l
     const uint32_t sh = (uint32_t)(a & 7) * 8;
     const uintptr_t idx = (a0 - hb.base) >> 3;  // huge when a0 lies before the buffer
     uint64_t q0, q1, q2;
-    if (hb.words && a0 >= hb.base && idx + 3 <= hb.words) {
+    // A refill costs a memory round trip whether one lane needs it or all do, and the lanes of a
+    // wavefront run out of buffered bytes at different headers: when one must go to memory, all
+    // that are here refill, so that the round trips of a wavefront coincide.
+    const bool hit = hb.words && a0 >= hb.base && idx + 3 <= hb.words;
+    if (__builtin_amdgcn_ballot_w64(!hit) == 0) {
         q0 = hb.slice[idx];
         q1 = hb.slice[idx + 1];
         q2 = hb.slice[idx + 2];
@@ -246,7 +252,8 @@ __device__ __forceinline__ uint32_t walk_headers(const uint8_t *s, uint64_t len,
         return true;
     };
     while (pos < end && n < max_runs) {
-        const bool guess = stride != 0 && stride == prev_stride;
+        // (short runs are better served by the buffered bytes than by guesses that go to memory)
+        const bool guess = stride > 8 * (HB_WORDS - 3) && stride == prev_stride;
         const uint64_t p1 = pos + stride, p2 = p1 + stride, p3 = p2 + stride;
         const bool h1 = guess && p1 < end, h2 = h1 && p2 < end, h3 = h2 && p3 < end;
         if (!h1) {
@@ -281,8 +288,12 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
     const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
     uint64_t *__restrict__ runs, uint32_t *__restrict__ group_first,
-    RunEntry *__restrict__ group_run, uint32_t n_group_slots, int full_table) {
+    RunEntry *__restrict__ group_run, uint32_t n_group_slots, int full_table,
+    uint64_t *__restrict__ staged, uint32_t staged_up_to) {
     __shared__ uint64_t header_bytes[SEG_BLOCK * HB_STRIDE];
+    constexpr uint32_t SB_HELD = 8;                // descriptors held per lane
+    constexpr uint32_t SB_STRIDE = SB_HELD + 1;    // odd pitch: spreads the LDS banks
+    __shared__ uint64_t staged_bytes[EMIT ? 1 : SEG_BLOCK * SB_STRIDE];
     uint64_t *lds_slice = header_bytes + threadIdx.x * HB_STRIDE;
     const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
     const bool valid = seg < n_seg;
@@ -303,17 +314,38 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
         uint64_t n_vals = 0;
         if (end > len || end < pos) status = SEG_MISALIGNED;
         if (valid && status == SEG_OK) {
+            // Staged descriptors leave in pieces of SB_HELD descriptors, collected in LDS: all lanes of the
+            // grid write at once, each to a place of its own, and 8-byte pieces of that many
+            // cache lines would each go out to memory as a partial line.
+            uint64_t *mine = staged ? staged + (uint64_t)seg * STAGED_RUNS : nullptr;
+            uint64_t *held = staged_bytes + threadIdx.x * SB_STRIDE;
             status = walk_headers(s, limit, pos, end, 0xFFFFFFFFu, is_signed, lds_slice, [&](const ParsedRun &r) {
+                if (mine && n_runs < STAGED_RUNS) {
+                    held[n_runs & (SB_HELD - 1)] = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes);
+                    if ((n_runs & (SB_HELD - 1)) == SB_HELD - 1) {
+                        u64x2 *dst = (u64x2 *)(mine + (n_runs - (SB_HELD - 1)));
+#pragma unroll
+                        for (uint32_t i = 0; i < SB_HELD / 2; i++) {
+                            u64x2 v;
+                            v.x = held[2 * i];
+                            v.y = held[2 * i + 1];
+                            dst[i] = v;
+                        }
+                    }
+                }
                 n_runs++;
                 n_vals += r.len;
                 last_len = r.len;
             });
+            if (mine && n_runs < STAGED_RUNS)
+                for (uint32_t k = n_runs & ~(SB_HELD - 1); k < n_runs; k++) mine[k] = held[k & (SB_HELD - 1)];
         }
         if (status == SEG_OK && pos != end && !last_seg) status = SEG_MISALIGNED;
         seg_publish(t, seg, n_seg, n_runs, last_len, status, n_vals);
     } else {
         if (!valid) return;
         const uint32_t n_runs = t.seg_count[seg].n_runs;
+        if (staged_up_to && n_runs <= staged_up_to) return;  // emitted from the staged descriptors
         const SegOffset so = seg_global_offset(t, seg);
         uint64_t out_off = so.val_off;
         uint32_t run_idx = so.run_off;
@@ -364,6 +396,88 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
     }
 }
 
+// EMIT for the segments whose descriptors the counting pass staged: one wavefront per segment, one
+// lane per run.  Nothing here waits on the header chain: a run's place follows from a wave scan of
+// the lengths, and the base / second field of a window's first run from parsing that one header.
+__global__ __launch_bounds__(256) void rlev2_emit_staged_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
+    const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
+    const uint64_t *__restrict__ staged, uint64_t *__restrict__ runs,
+    uint32_t *__restrict__ group_first, RunEntry *__restrict__ group_run, uint32_t n_group_slots,
+    int full_table) {
+    static_assert(STAGED_RUNS == 64, "one lane per staged run");
+    const uint32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (seg >= n_seg) return;
+    const uint32_t n_runs = t.seg_count[seg].n_runs;
+    if (n_runs > STAGED_RUNS) return;  // the walking kernel emits this one
+    const bool last_seg = seg + 1 == n_seg;
+    if (n_runs == 0 && !last_seg) return;
+    const SegOffset so = seg_global_offset(t, seg);
+    // the stream as this segment sees it (see rlev2_scan_kernel)
+    const uint64_t limit = seg_ends ? (seg_ends[seg] < len ? seg_ends[seg] : len) : len;
+    const bool live = lane < n_runs;
+    const uint64_t desc = live ? staged[(uint64_t)seg * STAGED_RUNS + lane] : 0;
+    const uint32_t rlen = live ? desc_len(desc) : 0;
+    uint32_t incl = rlen;  // inclusive scan of the lengths
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t u = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += u;
+    }
+    uint32_t prev_len = __shfl_up(rlen, 1);
+    if (lane == 0) prev_len = so.prev_len;
+    const uint64_t out_off = so.val_off + (incl - rlen);
+    const uint32_t run_idx = so.run_off + lane;
+    const uint64_t win = out_off >> WINDOW_SHIFT;
+    const bool first = live && ((out_off == 0) || (((out_off - prev_len) >> WINDOW_SHIFT) != win));
+    const bool single = first && ((out_off + rlen) >> WINDOW_SHIFT) != win;
+    const bool is_tail = last_seg && lane + 1 == (n_runs ? n_runs : 1u);  // the lane that writes the sentinel
+    // the header again, for a window's first run (base, second field) and for the end of the
+    // stream's last run; a Direct run has neither field
+    ParsedRun r;
+    r.base = 0;
+    r.aux = 0;
+    r.run_end = 0;
+    if (live && ((first && win < n_group_slots && desc_kind(desc) != KIND_DIRECT) || is_tail)) {
+        const uint64_t pos = desc_payload(desc) - desc_header_bytes(desc);
+        (void)parse_run(load_window(s, limit, pos), s, limit, pos, is_signed, r);  // parsed fine once already
+    }
+    if (live && (!single || full_table)) runs[run_idx] = desc;
+    if (first && win < n_group_slots) {
+        group_first[win] = run_idx;
+        RunEntry ge;
+        ge.desc = single ? desc | DESC_SINGLE : desc;
+        ge.out_off = out_off;
+        ge.base = r.base;
+        ge.aux = r.aux;
+        group_run[win] = ge;
+    }
+    if (is_tail) {
+        // sentinel: one-past-the-end run and the windows after the last run start (see
+        // rlev2_scan_kernel)
+        uint64_t pos = r.run_end;
+        if (n_runs == 0) {
+            pos = (entries && (seg > 0 || seg_ends)) ? entries[seg] : 0;
+            if (pos > len) pos = len;
+        }
+        const uint64_t end_off = out_off + rlen;
+        const uint32_t end_prev = n_runs ? rlen : so.prev_len;
+        const uint32_t end_idx = so.run_off + n_runs;
+        RunEntry e;
+        e.desc = make_desc(pos, KIND_SHORT_REPEAT, 0, 1, 0, 1);
+        e.out_off = end_off;
+        e.base = 0;
+        e.aux = 0;
+        runs[end_idx] = e.desc;
+        const uint64_t g_end = (end_off + WINDOW - 1) >> WINDOW_SHIFT;
+        uint64_t g = end_off == 0 ? 0 : ((end_off - end_prev) >> WINDOW_SHIFT) + 1;
+        for (; g <= g_end && g < n_group_slots; g++) {
+            group_first[g] = end_idx;
+            group_run[g] = e;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2: prefix sums over the per-workgroup totals of the counting pass -- one workgroup.
 // ---------------------------------------------------------------------------------------------
@@ -378,13 +492,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void block_totals_scan_kernel(SegTabl
     __shared__ uint32_t first_bad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) first_bad = 0xFFFFFFFFu;
+    __shared__ uint32_t most_runs;
+    if (threadIdx.x == 0) most_runs = 0;
+    uint32_t my_most = 0;
     uint64_t carry_vals = 0, carry_runs = 0, carry_key = 0;
     for (uint32_t base = 0; base < n_blocks; base += SCAN_THREADS) {
         const uint32_t b = base + threadIdx.x;
         BlockTotals bt;
         bt.n_vals = 0; bt.n_runs = 0; bt.last_len = 0; bt.bad_local_end = 0;
-        bt.bad_seg = 0xFFFFFFFFu; bt.bad_status = SEG_OK;
+        bt.bad_seg = 0xFFFFFFFFu; bt.bad_status = SEG_OK; bt.max_seg_runs = 0;
         if (b < n_blocks) bt = t.blk[b];
+        my_most = my_most > bt.max_seg_runs ? my_most : bt.max_seg_runs;
         uint64_t iv = bt.n_vals, ir = bt.n_runs;
         uint64_t ik = bt.n_runs ? (((uint64_t)b + 1) << 10) | bt.last_len : 0;
         for (int d = 1; d < 64; d <<= 1) {
@@ -423,6 +541,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void block_totals_scan_kernel(SegTabl
         carry_runs += tr;
         carry_key = carry_key > tk ? carry_key : tk;
     }
+    if (my_most) atomicMax(&most_runs, my_most);
     __syncthreads();
     if (threadIdx.x == 0) {
         ScanTotals tt;
@@ -430,6 +549,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void block_totals_scan_kernel(SegTabl
         tt.total_runs = carry_runs;
         tt.error = ORCD_OK;
         tt.error_seg = 0xFFFFFFFFu;
+        tt.max_seg_runs = most_runs;
         tt.pad = 0;
         if (first_bad != 0xFFFFFFFFu) {
             const BlockTotals bt = t.blk[first_bad];
@@ -553,7 +673,6 @@ __device__ __forceinline__ void payload_range(uint32_t kind, uint32_t w, uint32_
 
 // The decoded column is written once and not read back by this kernel: nontemporal stores keep
 // it from displacing the stream bytes and run tables in L2.
-typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void stream_store2(int64_t *dst, uint64_t v0, uint64_t v1) {
     u64x2 v;
     v.x = v0;
@@ -1139,10 +1258,11 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
 
 hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                               const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
-                              int is_signed, const SegTable &t) {
+                              int is_signed, const SegTable &t, uint64_t *staged) {
     const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
     rlev2_scan_kernel<false><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, seg_ends, n_seg,
-                                                          is_signed, t, nullptr, nullptr, nullptr, 0, 0);
+                                                          is_signed, t, nullptr, nullptr, nullptr, 0, 0,
+                                                          staged, 0);
     return hipGetLastError();
 }
 
@@ -1155,11 +1275,25 @@ hipError_t launch_block_totals_scan(hipStream_t st, const SegTable &t, uint32_t 
 hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                              const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                              int is_signed, const SegTable &t, uint64_t *runs, uint32_t *group_first,
-                             RunEntry *group_run, uint32_t n_group_slots, bool full_table) {
+                             RunEntry *group_run, uint32_t n_group_slots, bool full_table,
+                             uint32_t staged_up_to) {
     const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
     rlev2_scan_kernel<true><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, seg_ends, n_seg,
                                                          is_signed, t, runs, group_first, group_run,
-                                                         n_group_slots, full_table ? 1 : 0);
+                                                         n_group_slots, full_table ? 1 : 0, nullptr,
+                                                         staged_up_to);
+    return hipGetLastError();
+}
+
+hipError_t launch_rlev2_emit_staged(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                    const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
+                                    int is_signed, const SegTable &t, const uint64_t *staged,
+                                    uint64_t *runs, uint32_t *group_first, RunEntry *group_run,
+                                    uint32_t n_group_slots, bool full_table) {
+    const uint32_t blocks = (n_seg + 3) / 4;
+    rlev2_emit_staged_kernel<<<blocks, 256, 0, st>>>(stream, len, entries, seg_ends, n_seg, is_signed, t,
+                                                     staged, runs, group_first, group_run, n_group_slots,
+                                                     full_table ? 1 : 0);
     return hipGetLastError();
 }
 

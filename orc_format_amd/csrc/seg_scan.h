@@ -20,6 +20,8 @@ struct BlockTotals {
     uint64_t bad_local_end;   // values of the workgroup up to the end of its first stopped walk
     uint32_t bad_seg;         // that segment, or 0xFFFFFFFF
     uint32_t bad_status;
+    uint32_t max_seg_runs;    // most runs any one of the workgroup's segments holds
+    uint32_t pad;
 };
 
 struct BlockOffset {
@@ -49,11 +51,17 @@ __device__ __forceinline__ void seg_publish(const SegTable &t, uint32_t seg, uin
     __shared__ uint64_t w_vals[SEG_BLOCK / 64];
     __shared__ uint64_t w_key[SEG_BLOCK / 64];
     __shared__ uint32_t w_runs[SEG_BLOCK / 64];
+    __shared__ uint32_t w_max[SEG_BLOCK / 64];
     __shared__ uint32_t first_bad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool valid = seg < n_seg;
     if (!valid) { n_runs = 0; last_len = 0; status = SEG_OK; n_vals = 0; }
     if (threadIdx.x == 0) first_bad = 0xFFFFFFFFu;
+    uint32_t most = n_runs;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(most, d);
+        most = most > o ? most : o;
+    }
 
     // inclusive scans inside the wavefront: values, runs, and "most recent non-empty segment"
     // as a running maximum over (lane + 1, last_len)
@@ -70,7 +78,7 @@ __device__ __forceinline__ void seg_publish(const SegTable &t, uint32_t seg, uin
             ik = ik > uk ? ik : uk;
         }
     }
-    if (lane == 63) { w_vals[wave] = iv; w_runs[wave] = ir; w_key[wave] = ik; }
+    if (lane == 63) { w_vals[wave] = iv; w_runs[wave] = ir; w_key[wave] = ik; w_max[wave] = most; }
     __syncthreads();
     uint64_t pv = 0, pk = 0, tv = 0, tk = 0;
     uint32_t pr = 0, tr = 0;
@@ -111,6 +119,10 @@ __device__ __forceinline__ void seg_publish(const SegTable &t, uint32_t seg, uin
         t.blk[blockIdx.x].n_vals = tv;
         t.blk[blockIdx.x].n_runs = tr;
         t.blk[blockIdx.x].last_len = (uint32_t)(tk & 1023);
+        uint32_t m = 0;
+        for (int w = 0; w < SEG_BLOCK / 64; w++) m = m > w_max[w] ? m : w_max[w];
+        t.blk[blockIdx.x].max_seg_runs = m;
+        t.blk[blockIdx.x].pad = 0;
         if (fb == 0xFFFFFFFFu) {
             t.blk[blockIdx.x].bad_local_end = 0;
             t.blk[blockIdx.x].bad_seg = 0xFFFFFFFFu;

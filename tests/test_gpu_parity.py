@@ -175,6 +175,37 @@ def test_random_streams(gpu, oracle, signed, seed, n_runs, max_len):
     assert [(k, w, l) for k, w, l, _, _ in runs_gpu] == [(k, w, l) for k, w, l, _, _ in runs_cpu]
 
 
+@pytest.mark.parametrize("signed", [False, True])
+@pytest.mark.parametrize("tail_gap", [1, 64, 65, 300])
+def test_irregular_entry_points(gpu, oracle, signed, tail_gap):
+    """Many segments of very different sizes: those of up to 64 runs are emitted from the
+    descriptors the counting pass kept, longer ones by a second walk, in one run table."""
+    rng = np.random.default_rng(500 + tail_gap + signed)
+    stream, expect, starts = enc.random_stream(rng, 6000, signed, max_len=40)
+    picks, k = [0], 0
+    while True:
+        k += int(rng.choice([1, 2, 5, 63, 64, 65, 130]))
+        if k >= len(starts) - tail_gap:
+            break
+        picks.append(k)
+    picks.append(len(starts) - tail_gap)
+    assert len(picks) >= 64
+    entries = np.array([starts[i] for i in picks], dtype=np.uint64)
+    rc, out, _ = gpu.rlev2(stream, expect.size, signed, entries)
+    assert rc == 0 and (out == expect).all()
+    # fewer values than the stream holds: the tail segments are not wanted
+    for n in (expect.size // 2, expect.size - 1, 513):
+        rc, out, _ = gpu.rlev2(stream, n, signed, entries)
+        assert rc == 0 and (out == expect[:n]).all()
+    # an entry point at the very end of the stream: a last segment without runs
+    rc, out, _ = gpu.rlev2(stream, expect.size, signed, np.append(entries, np.uint64(len(stream))))
+    assert rc == 0 and (out == expect).all()
+    if not signed:
+        rc, runs_cpu = oracle.runs(stream, expect.size)
+        rc, runs_gpu = gpu.runs(stream, expect.size, entries)
+        assert rc == 0 and [(k, w, l) for k, w, l, _, _ in runs_gpu] == [(k, w, l) for k, w, l, _, _ in runs_cpu]
+
+
 @pytest.mark.parametrize("kind", [1, 3])
 @pytest.mark.parametrize("width", enc.WIDTHS)
 def test_every_width(gpu, oracle, kind, width):
