@@ -409,15 +409,19 @@ __global__ __launch_bounds__(256) void rlev2_emit_staged_kernel(
     const uint32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     if (seg >= n_seg) return;
+    // everything the wavefront needs from memory is asked for at once (a staged slot that was
+    // never written holds whatever it held; it is not looked at)
+    const uint64_t staged_word = staged[(uint64_t)seg * STAGED_RUNS + lane];
     const uint32_t n_runs = t.seg_count[seg].n_runs;
+    const SegOffset so = seg_global_offset(t, seg);
+    const uint64_t seg_end = seg_ends ? seg_ends[seg] : len;
     if (n_runs > STAGED_RUNS) return;  // the walking kernel emits this one
     const bool last_seg = seg + 1 == n_seg;
     if (n_runs == 0 && !last_seg) return;
-    const SegOffset so = seg_global_offset(t, seg);
     // the stream as this segment sees it (see rlev2_scan_kernel)
-    const uint64_t limit = seg_ends ? (seg_ends[seg] < len ? seg_ends[seg] : len) : len;
+    const uint64_t limit = seg_end < len ? seg_end : len;
     const bool live = lane < n_runs;
-    const uint64_t desc = live ? staged[(uint64_t)seg * STAGED_RUNS + lane] : 0;
+    const uint64_t desc = live ? staged_word : 0;
     const uint32_t rlen = live ? desc_len(desc) : 0;
     uint32_t incl = rlen;  // inclusive scan of the lengths
     for (int d = 1; d < 64; d <<= 1) {
