@@ -40,7 +40,8 @@ class ColumnData(C.Structure):
     _fields_ = [("type_kind", C.c_int), ("on_device", C.c_int), ("row_aligned", C.c_int),
                 ("num_rows", C.c_uint64), ("num_values", C.c_uint64), ("num_slots", C.c_uint64),
                 ("validity", C.c_void_p), ("values", C.c_void_p), ("value_size", C.c_size_t),
-                ("offsets", C.c_void_p), ("bytes", C.c_void_p), ("num_bytes", C.c_uint64)]
+                ("offsets", C.c_void_p), ("bytes", C.c_void_p), ("num_bytes", C.c_uint64),
+                ("owner", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/orcd.h declares

@@ -6,6 +6,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
 #include <thread>
 #include <vector>
 
@@ -57,6 +61,12 @@ struct orcd_ctx {
     uint64_t *h_scalars = nullptr;   // pinned, 8 words
     uint8_t *h_stage[N_READERS] = {};  // pinned chunks for whole-stripe reads, allocated on first use
     hipEvent_t ev_stage[N_READERS] = {};
+    // Result arrays and per-call temporaries of the column calls: released blocks are kept and
+    // handed out again (see dev_alloc).
+    std::mutex cache_lock;
+    std::multimap<size_t, void *> cache_free;       // capacity -> block
+    std::unordered_map<void *, size_t> cache_live;  // block in use -> capacity
+    size_t cache_held = 0;                          // bytes in cache_free
     hipError_t last_hip = hipSuccess;
 };
 
@@ -385,6 +395,7 @@ int orcd_ctx_destroy(orcd_ctx *c) {
         if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
         if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
     }
+    for (auto &kv : c->cache_free) (void)hipFree(kv.second);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return ORCD_OK;
@@ -1063,10 +1074,46 @@ struct ColumnStreams {
     }
 };
 
+// Device memory for a result array or a temporary of the column calls.  hipMalloc and hipFree of
+// a block of 10 MB and more cost 20-100 and 150-190 microseconds (hipFree waits for the device,
+// too; the runtime's own memory pools give large blocks back just the same), and a column takes
+// a handful of each: released blocks are kept by the context and handed out again -- to work that
+// is queued on the context's stream after whatever used them before, so no wait is needed.
+constexpr size_t CACHE_MAX_HELD = 64ull << 30;  // beyond this, released blocks go back to the runtime
+
 int dev_alloc(orcd_ctx *c, size_t bytes, void **p) {
     *p = nullptr;
-    HIP_TRY(c, hipMalloc(p, bytes ? bytes : 16));
+    const size_t want = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+    std::lock_guard<std::mutex> g(c->cache_lock);
+    auto it = c->cache_free.lower_bound(want);
+    if (it != c->cache_free.end() && it->first <= want + want / 2 + 4096) {  // a block that fits without much waste
+        *p = it->second;
+        c->cache_held -= it->first;
+        c->cache_live[*p] = it->first;
+        c->cache_free.erase(it);
+        return ORCD_OK;
+    }
+    HIP_TRY(c, hipMalloc(p, want));
+    c->cache_live[*p] = want;
     return ORCD_OK;
+}
+
+void dev_free(orcd_ctx *c, void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(c->cache_lock);
+    auto it = c->cache_live.find(p);
+    if (it == c->cache_live.end()) {  // not one of ours
+        (void)hipFree(p);
+        return;
+    }
+    const size_t cap = it->second;
+    c->cache_live.erase(it);
+    if (c->cache_held + cap > CACHE_MAX_HELD) {
+        (void)hipFree(p);
+        return;
+    }
+    c->cache_free.emplace(cap, p);
+    c->cache_held += cap;
 }
 
 // Moves a device result array to where the caller wants it: stays (device) or a malloc'd copy.
@@ -1077,12 +1124,12 @@ int deliver(orcd_ctx *c, void *d_ptr, size_t bytes, bool out_dev, void **result)
     }
     void *h = malloc(bytes ? bytes : 1);
     if (!h) {
-        (void)hipFree(d_ptr);
+        dev_free(c, d_ptr);
         return ORCD_HIP_ERROR;
     }
     hipError_t e = bytes ? hipMemcpyAsync(h, d_ptr, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_ptr);
+    dev_free(c, d_ptr);
     if (e != hipSuccess) {
         free(h);
         c->last_hip = e;
@@ -1094,14 +1141,14 @@ int deliver(orcd_ctx *c, void *d_ptr, size_t bytes, bool out_dev, void **result)
 
 // Device arrays of a column under construction; whatever is still set at scope exit is released.
 struct Pending {
+    orcd_ctx *c = nullptr;
     void *validity = nullptr, *values = nullptr, *offsets = nullptr, *bytes = nullptr, *tmp = nullptr,
          *tmp2 = nullptr;
-    Pending() = default;
+    explicit Pending(orcd_ctx *ctx) : c(ctx) {}
     Pending(const Pending &) = delete;
     Pending &operator=(const Pending &) = delete;
     ~Pending() {
-        for (void *p : {validity, values, offsets, bytes, tmp, tmp2})
-            if (p) (void)hipFree(p);
+        for (void *p : {validity, values, offsets, bytes, tmp, tmp2}) dev_free(c, p);
     }
 };
 
@@ -1235,14 +1282,14 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
         if (p.values) {
             ORCD_TRY(dev_alloc(c, rows * value_size, &aligned));
             std::swap(aligned, p.values);  // p.values: the row-aligned array; aligned: the dense one
-            if (p.tmp) (void)hipFree(p.tmp);
+            dev_free(c, p.tmp);
             p.tmp = aligned;                // released with the other temporaries
             ORCD_TRY(scatter_device(c, (const uint8_t *)p.validity, rows, aligned, n_values, value_size,
                                     p.values, false));
         } else {
             ORCD_TRY(dev_alloc(c, (rows + 1) * 8, &aligned));
             std::swap(aligned, p.offsets);
-            if (p.tmp) (void)hipFree(p.tmp);
+            dev_free(c, p.tmp);
             p.tmp = aligned;
             ORCD_TRY(scatter_device(c, (const uint8_t *)p.validity, rows, aligned, n_values, 8, p.offsets, true));
             HIP_TRY(c, hipMemcpyAsync((int64_t *)p.offsets + rows, (int64_t *)aligned + n_values, 8,
@@ -1260,6 +1307,7 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
     out->num_slots = slots;
     out->value_size = value_size;
     out->num_bytes = num_bytes;
+    out->owner = out_dev ? c : nullptr;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     void *r;
     int rc = deliver(c, p.validity, rows, out_dev, &r);
@@ -1286,7 +1334,7 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
 
 int decode_column_impl(orcd_ctx *c, orcd_file *file, orcd_column *col, int type_kind, unsigned flags,
                        orcd_column_data *out) {
-    Pending p;
+    Pending p(c);
     uint64_t n_values = 0;
     const ColumnStreams cs{file, col, nullptr};
     ORCD_TRY(column_validity(c, cs, p, &n_values));
@@ -1300,12 +1348,13 @@ struct StripeJob {
     uint64_t n_values = 0;
     bool have_validity = false, batched = false;
     Pending p;
+    explicit StripeJob(orcd_ctx *c) : p(c) {}
 };
 
 constexpr size_t STAGE_CHUNK = 8u << 20;
-// Streams up to this size share one set of launches with their peers; a larger one gains nothing
-// from it (a decode call costs ~50 microseconds whatever its size) and is decoded where it lies.
-constexpr uint64_t BATCH_STREAM_MAX = 4u << 20;
+// Streams up to this size share one set of launches -- and one wait for the header totals -- with
+// their peers (measured on a 26-column file: the larger the limit, the faster, up to here).
+constexpr uint64_t BATCH_STREAM_MAX = 64u << 20;
 
 // File bytes [file_off, file_off + len) -> d_dst.  A single thread reading from the page cache
 // moves a few GB/s, far less than the host-to-device link: N_READERS threads take the chunks in
@@ -1400,7 +1449,7 @@ struct StreamBatch {
 
 int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
                        const uint32_t *columns, size_t n_columns, unsigned flags, orcd_column_data *out,
-                       std::vector<StripeJob> &jobs, Pending &stripe_mem) {
+                       std::vector<std::unique_ptr<StripeJob>> &jobs, Pending &stripe_mem) {
     // 1. the bytes the columns' streams span, read once and copied once to the device
     orcd_stripe_info si;
     ORCD_TRY(orcd_file_stripe(file, stripe, &si));
@@ -1408,8 +1457,8 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     for (size_t i = 0; i < n_columns; i++) {
         if (columns[i] >= wanted.size()) return ORCD_INVALID_COLUMN;
         wanted[columns[i]] = true;
-        jobs[i].type_kind = orcd_file_type_kind(file, columns[i]);
-        ORCD_TRY(orcd_stripe_column_open(file, stripe, footer, columns[i], &jobs[i].col));
+        (*jobs[i]).type_kind = orcd_file_type_kind(file, columns[i]);
+        ORCD_TRY(orcd_stripe_column_open(file, stripe, footer, columns[i], &(*jobs[i]).col));
     }
     StripeBytes sb;
     sb.lo = ~0ull;
@@ -1432,8 +1481,8 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
         StreamBatch batch;
         uint64_t arena_bytes = 0;
         for (size_t i = 0; i < n_columns; i++) {
-            const ColumnStreams cs{file, jobs[i].col, &sb};
-            const uint64_t rows = orcd_column_number_of_rows(jobs[i].col);
+            const ColumnStreams cs{file, (*jobs[i]).col, &sb};
+            const uint64_t rows = orcd_column_number_of_rows((*jobs[i]).col);
             const uint8_t *b;
             size_t l, n_ent;
             const uint64_t *ent;
@@ -1452,7 +1501,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
             if (rc == ORCD_OK) {
                 uint64_t pos = 0;
                 for (size_t k = 0; k < batch.owner.size(); k++) {
-                    StripeJob &j = jobs[batch.owner[k]];
+                    StripeJob &j = (*jobs[batch.owner[k]]);
                     const uint64_t rows = batch.slices[k].num_values;
                     ORCD_TRY(dev_alloc(c, rows, &j.p.validity));
                     HIP_TRY(c, hipMemcpyAsync(j.p.validity, (uint8_t *)stripe_mem.tmp2 + pos, rows,
@@ -1467,30 +1516,30 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
         }
     }
     for (size_t i = 0; i < n_columns; i++) {
-        if (jobs[i].have_validity) continue;
-        const ColumnStreams cs{file, jobs[i].col, &sb};
-        ORCD_TRY(column_validity(c, cs, jobs[i].p, &jobs[i].n_values));
+        if ((*jobs[i]).have_validity) continue;
+        const ColumnStreams cs{file, (*jobs[i]).col, &sb};
+        ORCD_TRY(column_validity(c, cs, (*jobs[i]).p, &(*jobs[i]).n_values));
     }
     // 3. the small DATA streams of the integer columns in one set of launches
     {
         StreamBatch batch;
         uint64_t total = 0;
         for (size_t i = 0; i < n_columns; i++) {
-            if (!is_int_kind(jobs[i].type_kind) || jobs[i].n_values == 0) continue;
-            const ColumnStreams cs{file, jobs[i].col, &sb};
+            if (!is_int_kind((*jobs[i]).type_kind) || (*jobs[i]).n_values == 0) continue;
+            const ColumnStreams cs{file, (*jobs[i]).col, &sb};
             const uint8_t *b;
             size_t l, n_ent;
             const uint64_t *ent;
             if (cs.get(ORCD_STREAM_DATA, &b, &l, &ent, &n_ent, true) != ORCD_OK) continue;  // reported per column below
             if (l > BATCH_STREAM_MAX) continue;
-            batch.add(i, b, l, jobs[i].n_values, ent, n_ent);
-            total += jobs[i].n_values;
+            batch.add(i, b, l, (*jobs[i]).n_values, ent, n_ent);
+            total += (*jobs[i]).n_values;
         }
         if (batch.slices.size() > 1) {
             const uint8_t *d_first = batch.finish();
             void *arena = nullptr;  // (the validity arena may still feed copies on the stream)
             ORCD_TRY(dev_alloc(c, total * 8, &arena));
-            Pending hold;
+            Pending hold(c);
             hold.tmp = arena;
             const int rc = orcd_rlev2_decode_batch(c, d_first, batch.hi - batch.lo, batch.slices.data(),
                                                    batch.slices.size(), (int64_t *)arena, nullptr,
@@ -1498,7 +1547,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
             if (rc == ORCD_OK) {
                 uint64_t pos = 0;
                 for (size_t k = 0; k < batch.owner.size(); k++) {
-                    StripeJob &j = jobs[batch.owner[k]];
+                    StripeJob &j = (*jobs[batch.owner[k]]);
                     ORCD_TRY(dev_alloc(c, j.n_values * 8, &j.p.values));
                     HIP_TRY(c, hipMemcpyAsync(j.p.values, (int64_t *)arena + pos, j.n_values * 8,
                                               hipMemcpyDeviceToDevice, c->stream));
@@ -1513,8 +1562,8 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     }
     // 4. everything else, column by column
     for (size_t i = 0; i < n_columns; i++) {
-        const ColumnStreams cs{file, jobs[i].col, &sb};
-        ORCD_TRY(column_values(c, cs, jobs[i].type_kind, flags, jobs[i].p, jobs[i].n_values, jobs[i].batched,
+        const ColumnStreams cs{file, (*jobs[i]).col, &sb};
+        ORCD_TRY(column_values(c, cs, (*jobs[i]).type_kind, flags, (*jobs[i]).p, (*jobs[i]).n_values, (*jobs[i]).batched,
                                &out[i]));
     }
     return ORCD_OK;
@@ -1528,12 +1577,13 @@ int orcd_decode_stripe(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     for (size_t i = 0; i < n_columns; i++) memset(&out[i], 0, sizeof(out[i]));
     if (orcd_file_compression(file) != 0) return ORCD_UNSUPPORTED;  // chunk framing is not decoded here
     DeviceGuard g(c->device);
-    std::vector<StripeJob> jobs(n_columns);
-    Pending stripe_mem;  // the stripe's bytes on the device, and the validity arena
+    std::vector<std::unique_ptr<StripeJob>> jobs;
+    for (size_t i = 0; i < n_columns; i++) jobs.emplace_back(new StripeJob(c));
+    Pending stripe_mem(c);  // the stripe's bytes on the device, and the validity arena
     const int rc = decode_stripe_impl(c, file, stripe, footer, columns, n_columns, flags, out, jobs, stripe_mem);
     (void)hipStreamSynchronize(c->stream);  // before the device buffers of this call are released
     for (auto &j : jobs)
-        if (j.col) orcd_column_free(j.col);
+        if (j->col) orcd_column_free(j->col);
     if (rc != ORCD_OK)
         for (size_t i = 0; i < n_columns; i++) orcd_column_data_free(&out[i]);
     return rc;
@@ -1560,8 +1610,9 @@ void orcd_column_data_free(orcd_column_data *d) {
     if (!d) return;
     for (void *p : {(void *)d->validity, d->values, (void *)d->offsets, (void *)d->bytes}) {
         if (!p) continue;
-        if (d->on_device) (void)hipFree(p);
-        else free(p);
+        if (!d->on_device) free(p);
+        else if (d->owner) dev_free(d->owner, p);  // back to the context that made it
+        else (void)hipFree(p);
     }
     memset(d, 0, sizeof(*d));
 }
