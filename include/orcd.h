@@ -263,10 +263,14 @@ int orcd_column_encoding(const orcd_column *column, int *kind, uint32_t *diction
 uint64_t orcd_column_number_of_rows(const orcd_column *column);
 /* For readers that fetch a whole stripe at once (one read, one copy to the device) and decode its
  * streams where they lie: a column handle without the column's bytes (orcd_column_get_stream then
- * fails; encoding, row count and entry points work), the place of one of its streams as an offset
- * from the start of the stripe, and a plain positioned read of file bytes. */
+ * fails; encoding, row count and entry points work), the region orcd_read_stripe_column would read
+ * and the place of one of its streams inside it -- both as offsets from the start of the stripe,
+ * and found the way the crate finds them (the region starts at the column's first stream and its
+ * streams follow one another, src/read/mod.rs:129-144, column.rs:38-55) -- and a plain positioned
+ * read of file bytes. */
 int orcd_stripe_column_open(orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
                             uint32_t column, orcd_column **out);
+int orcd_column_region(const orcd_column *column, uint64_t *offset, uint64_t *len);
 int orcd_column_stream_range(const orcd_column *column, int kind, uint64_t *offset, uint64_t *len);
 int orcd_file_read_at(orcd_file *file, uint64_t offset, uint64_t len, uint8_t *dst);
 /* Run-header entry points for orcd_rlev2_decode / orcd_byte_rle_decode taken from the column's

@@ -88,6 +88,7 @@ SIGNATURES = {
     "orcd_column_number_of_rows": (C.c_uint64, [P]),
     "orcd_column_entry_points": (C.c_int, [P, P, C.c_int, C.POINTER(P), C.POINTER(SZ)]),
     "orcd_stripe_column_open": (C.c_int, [P, SZ, P, C.c_uint32, C.POINTER(P)]),
+    "orcd_column_region": (C.c_int, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "orcd_column_stream_range": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "orcd_file_read_at": (C.c_int, [P, C.c_uint64, C.c_uint64, P]),
     "orcd_scatter_valid": (C.c_int, [P, P, SZ, P, SZ, SZ, P, C.c_uint]),

@@ -1453,23 +1453,19 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     // 1. the bytes the columns' streams span, read once and copied once to the device
     orcd_stripe_info si;
     ORCD_TRY(orcd_file_stripe(file, stripe, &si));
-    std::vector<bool> wanted(orcd_file_num_types(file), false);
     for (size_t i = 0; i < n_columns; i++) {
-        if (columns[i] >= wanted.size()) return ORCD_INVALID_COLUMN;
-        wanted[columns[i]] = true;
+        if (columns[i] >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
         (*jobs[i]).type_kind = orcd_file_type_kind(file, columns[i]);
         ORCD_TRY(orcd_stripe_column_open(file, stripe, footer, columns[i], &(*jobs[i]).col));
     }
     StripeBytes sb;
     sb.lo = ~0ull;
-    const size_t n_streams = orcd_stripe_footer_num_streams(footer);
-    for (size_t k = 0; k < n_streams; k++) {
-        orcd_stream_info info;
-        ORCD_TRY(orcd_stripe_footer_stream(footer, k, &info));
-        if (info.kind == ORCD_STREAM_ROW_INDEX || info.column >= wanted.size() || !wanted[info.column]) continue;
-        if (info.offset + info.length < info.offset) return ORCD_OUT_OF_SPEC;
-        sb.lo = std::min(sb.lo, info.offset);
-        sb.hi = std::max(sb.hi, info.offset + info.length);
+    for (size_t i = 0; i < n_columns; i++) {
+        uint64_t off = 0, n = 0;
+        ORCD_TRY(orcd_column_region((*jobs[i]).col, &off, &n));
+        if (off + n < off) return ORCD_OUT_OF_SPEC;
+        sb.lo = std::min(sb.lo, off);
+        sb.hi = std::max(sb.hi, off + n);
     }
     if (sb.lo > sb.hi) sb.lo = sb.hi = 0;
     ORCD_TRY(dev_alloc(c, sb.hi - sb.lo, &stripe_mem.tmp));

@@ -145,6 +145,7 @@ struct orcd_column {
     const orcd_stripe_footer *footer = nullptr;
     // entry points per stream kind, filled on demand from the ROW_INDEX stream
     bool index_loaded = false;
+    int index_status = ORCD_OK;  // what loading the ROW_INDEX entry points came to (kept: asked once)
     std::vector<uint64_t> entries[8];
 };
 
@@ -489,13 +490,42 @@ int orcd_stripe_column_open(orcd_file *f, size_t stripe, const orcd_stripe_foote
     return ORCD_OK;
 }
 
+int orcd_column_region(const orcd_column *col, uint64_t *offset, uint64_t *len) {
+    if (!col || !offset || !len) return ORCD_INVALID_ARGUMENT;
+    // what read_stripe_column reads: from the column's first non-ROW_INDEX stream, as many bytes
+    // as its streams hold together (src/read/mod.rs:129-144)
+    bool found = false;
+    uint64_t start = 0, length = 0;
+    for (const auto &s : col->footer->streams) {
+        if (s.column != col->column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
+        if (!found) {
+            found = true;
+            start = s.offset;
+        }
+        length += s.length;
+    }
+    if (!found) return ORCD_INVALID_COLUMN;
+    *offset = start;
+    *len = length;
+    return ORCD_OK;
+}
+
 int orcd_column_stream_range(const orcd_column *col, int kind, uint64_t *offset, uint64_t *len) {
     if (!col || !offset || !len) return ORCD_INVALID_ARGUMENT;
+    uint64_t region = 0, region_len = 0;
+    const int rc = orcd_column_region(col, &region, &region_len);
+    if (rc != ORCD_OK) return rc;
+    // the place orcd_column_get_stream finds the stream at: a running offset over the column's
+    // streams inside its region (src/read/column.rs:38-55)
+    uint64_t start = 0;
     for (const auto &s : col->footer->streams) {
-        if (s.column != col->column || (int)s.kind != kind || s.kind == ORCD_STREAM_ROW_INDEX) continue;
-        *offset = s.offset;
-        *len = s.length;
-        return ORCD_OK;
+        if (s.column != col->column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
+        if ((int)s.kind == kind) {
+            *offset = region + start;
+            *len = s.length;
+            return ORCD_OK;
+        }
+        start += s.length;
     }
     return ORCD_INVALID_KIND;
 }
@@ -536,9 +566,11 @@ int orcd_column_entry_points(orcd_file *f, orcd_column *col, int kind, const uin
                              size_t *n_entries) {
     if (!f || !col || !entries || !n_entries || kind < 0 || kind >= 8) return ORCD_INVALID_ARGUMENT;
     if (!col->index_loaded) {
-        const int rc = load_entry_points(f, col);
-        if (rc != ORCD_OK) return rc;
+        col->index_status = load_entry_points(f, col);
+        if (col->index_status != ORCD_OK)
+            for (auto &e : col->entries) e.clear();
     }
+    if (col->index_status != ORCD_OK) return col->index_status;
     *entries = col->entries[kind].data();
     *n_entries = col->entries[kind].size();
     return ORCD_OK;
