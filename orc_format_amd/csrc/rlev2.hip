@@ -230,8 +230,9 @@ __device__ __forceinline__ Window16 buffered_window(const uint8_t *s, uint64_t l
 // parsed -- so a plain walk pays one memory round trip per run.  Two ways around that:
 //  * long runs of equal size (the bulk of a long column): every round loads the header at `pos`
 //    together with three more at pos + k * (size of the previous run) and parses as many of the
-//    four as the chain confirms.  A wrong guess costs the extra loads, so the guessing is switched
-//    on by two consecutive runs of equal size and off by the first that differs;
+//    four as the chain confirms.  A wrong guess costs the extra loads, so the guessing is
+//    switched on by the segment's first run, kept on by runs of equal size and switched off by
+//    the first that differs;
 //  * short runs: the bytes fetched for one header hold the next ones too (buffered_window).
 template <typename Consume>
 __device__ __forceinline__ uint32_t walk_headers(const uint8_t *s, uint64_t len, uint64_t &pos,
@@ -251,28 +252,37 @@ __device__ __forceinline__ uint32_t walk_headers(const uint8_t *s, uint64_t len,
         n++;
         return true;
     };
+    constexpr int GUESS = 4;  // headers fetched per round while the guesses come true
     while (pos < end && n < max_runs) {
         // (short runs are better served by the buffered bytes than by guesses that go to memory)
-        const bool guess = stride > 8 * (HB_WORDS - 3) && stride == prev_stride;
-        const uint64_t p1 = pos + stride, p2 = p1 + stride, p3 = p2 + stride;
-        const bool h1 = guess && p1 < end, h2 = h1 && p2 < end, h3 = h2 && p3 < end;
-        if (!h1) {
+        const bool guess = stride > 8 * (HB_WORDS - 3) && (n == 1 || stride == prev_stride);
+        if (!(guess && pos + stride < end)) {
             // fetch ahead only where the last run was short enough for the next header to be near
             const Window16 w0 = buffered_window(s, len, pos, hb, stride <= 8 * (HB_WORDS - 3));
             if (!step(w0)) break;
             continue;
         }
-        const Window16 w0 = load_window(s, len, pos);
-        const Window16 w1 = load_window(s, len, p1);
-        const Window16 w2 = load_window(s, len, h2 ? p2 : pos);
-        const Window16 w3 = load_window(s, len, h3 ? p3 : pos);
-        if (!step(w0)) break;
-        if (!(pos == p1 && n < max_runs)) continue;
-        if (!step(w1)) break;
-        if (!(h2 && pos == p2 && n < max_runs)) continue;
-        if (!step(w2)) break;
-        if (!(h3 && pos == p3 && n < max_runs)) continue;
-        if (!step(w3)) break;
+        // header k of the round is expected at pos + k * stride; one past the segment's end is
+        // replaced by a re-read of the first (select on the address, not on the load)
+        const uint64_t p0 = pos, st = stride;
+        Window16 w[GUESS];
+#pragma unroll
+        for (int k = 0; k < GUESS; k++) {
+            const uint64_t pk = p0 + (uint64_t)k * st;
+            w[k] = load_window(s, len, pk < end ? pk : p0);
+        }
+        bool go = true;
+#pragma unroll
+        for (int k = 0; k < GUESS; k++) {
+            if (!go) continue;
+            // still on the guessed chain, inside the segment, and wanted?
+            if (k > 0 && !(pos == p0 + (uint64_t)k * st && pos < end && n < max_runs)) {
+                go = false;
+                continue;
+            }
+            if (!step(w[k])) go = false;
+        }
+        if (status != SEG_OK) break;
     }
     return status;
 }
