@@ -243,7 +243,7 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
         HIP_TRY(c, launch_rlev2_emit_staged(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed,
                                             sr.table, (const uint64_t *)staged, (uint64_t *)runs,
                                             (uint32_t *)groups, (RunEntry *)group_runs, (uint32_t)n_slots,
-                                            full_table));
+                                            full_table, sr.totals.max_seg_runs));
     if (!staged || sr.totals.max_seg_runs > STAGED_RUNS)
         HIP_TRY(c, launch_rlev2_emit(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, sr.table,
                                      (uint64_t *)runs, (uint32_t *)groups, (RunEntry *)group_runs,
@@ -287,9 +287,11 @@ int byte_rle_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
     const uint64_t *seg_ends = n_entries ? d_seg_ends : nullptr;
+    void *staged = nullptr;  // as in rlev2_table
+    if (n_seg >= 64) ORCD_TRY(ensure(c, SLOT_STAGED_RUNS, (size_t)n_seg * STAGED_RUNS * sizeof(uint64_t), &staged));
     ScanResult sr;
     ORCD_TRY(count_and_scan(c, n_seg, num_bytes, [&](const SegTable &st) {
-        return launch_byte_rle_count(c->stream, d_stream, len, entries, seg_ends, n_seg, st);
+        return launch_byte_rle_count(c->stream, d_stream, len, entries, seg_ends, n_seg, st, (uint64_t *)staged);
     }, &sr));
     mark(c, 1);
     if (seg_table) *seg_table = sr.table;
@@ -300,8 +302,14 @@ int byte_rle_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_
     void *runs, *wins;
     ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(ByteRun), &runs));
     ORCD_TRY(ensure(c, SLOT_GROUPS, n_slots * sizeof(uint32_t), &wins));
-    HIP_TRY(c, launch_byte_rle_emit(c->stream, d_stream, len, entries, seg_ends, n_seg, sr.table,
-                                    (ByteRun *)runs, (uint32_t *)wins, (uint32_t)n_slots));
+    if (staged)
+        HIP_TRY(c, launch_byte_rle_emit_staged(c->stream, n_seg, sr.table, (const uint64_t *)staged,
+                                               (ByteRun *)runs, (uint32_t *)wins, (uint32_t)n_slots,
+                                               sr.totals.max_seg_runs));
+    if (!staged || sr.totals.max_seg_runs > STAGED_RUNS)
+        HIP_TRY(c, launch_byte_rle_emit(c->stream, d_stream, len, entries, seg_ends, n_seg, sr.table,
+                                        (ByteRun *)runs, (uint32_t *)wins, (uint32_t)n_slots,
+                                        staged ? STAGED_RUNS : 0));
     mark(c, 2);
     t->runs = (const ByteRun *)runs;
     t->win_first = (const uint32_t *)wins;

@@ -122,7 +122,14 @@ hipError_t launch_rlev2_emit_staged(hipStream_t st, const uint8_t *stream, uint6
                                     const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                                     int is_signed, const SegTable &t, const uint64_t *staged,
                                     uint64_t *runs, uint32_t *group_first, RunEntry *group_run,
-                                    uint32_t n_group_slots, bool full_table);
+                                    uint32_t n_group_slots, bool full_table, uint32_t max_seg_runs);
+// lanes the staged emit kernels give a segment: the power of two from 8 to 64 that holds the
+// most runs any segment has (segments with more than STAGED_RUNS are not theirs)
+inline uint32_t staged_group_lanes(uint32_t max_seg_runs) {
+    uint32_t g = 8;
+    while (g < STAGED_RUNS && g < max_seg_runs) g <<= 1;
+    return g;
+}
 // Parallel check of a guessed header chain (see rlev2.hip): the size of the run at `pos`, and the
 // first k < n for which p + k * stride is not the header of a run of `stride` bytes (*first_fail
 // must hold n or more beforehand).
@@ -154,13 +161,17 @@ hipError_t launch_rlev2_group_sums(hipStream_t st, const Rlev2Table &t, uint64_t
 hipError_t launch_rlev2_offsets(hipStream_t st, const Rlev2Table &t, const uint64_t *group_prefix,
                                 int64_t *offsets);
 
+// (staged, staged_up_to: as for the RLE v2 passes; a staged word is the run's ByteRun::src)
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                                  const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
-                                 const SegTable &t);
+                                 const SegTable &t, uint64_t *staged);
 hipError_t launch_byte_rle_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                                 const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                                 const SegTable &t, ByteRun *runs, uint32_t *win_first,
-                                uint32_t n_win_slots);
+                                uint32_t n_win_slots, uint32_t staged_up_to);
+hipError_t launch_byte_rle_emit_staged(hipStream_t st, uint32_t n_seg, const SegTable &t,
+                                       const uint64_t *staged, ByteRun *runs, uint32_t *win_first,
+                                       uint32_t n_win_slots, uint32_t max_seg_runs);
 hipError_t launch_count_nonzero_slices(hipStream_t st, const uint8_t *bytes, const uint64_t *start,
                                        const uint64_t *count, uint32_t n_slices, uint64_t *out);
 // slots of win_first for a stream of total_bytes decoded bytes

@@ -301,8 +301,6 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
     RunEntry *__restrict__ group_run, uint32_t n_group_slots, int full_table,
     uint64_t *__restrict__ staged, uint32_t staged_up_to) {
     __shared__ uint64_t header_bytes[SEG_BLOCK * HB_STRIDE];
-    constexpr uint32_t SB_HELD = 8;                // descriptors held per lane
-    constexpr uint32_t SB_STRIDE = SB_HELD + 1;    // odd pitch: spreads the LDS banks
     __shared__ uint64_t staged_bytes[EMIT ? 1 : SEG_BLOCK * SB_STRIDE];
     uint64_t *lds_slice = header_bytes + threadIdx.x * HB_STRIDE;
     const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
@@ -324,31 +322,15 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
         uint64_t n_vals = 0;
         if (end > len || end < pos) status = SEG_MISALIGNED;
         if (valid && status == SEG_OK) {
-            // Staged descriptors leave in pieces of SB_HELD descriptors, collected in LDS: all lanes of the
-            // grid write at once, each to a place of its own, and 8-byte pieces of that many
-            // cache lines would each go out to memory as a partial line.
-            uint64_t *mine = staged ? staged + (uint64_t)seg * STAGED_RUNS : nullptr;
-            uint64_t *held = staged_bytes + threadIdx.x * SB_STRIDE;
+            StagedWriter keep = {staged ? staged + (uint64_t)seg * STAGED_RUNS : nullptr,
+                                 staged_bytes + threadIdx.x * SB_STRIDE};
             status = walk_headers(s, limit, pos, end, 0xFFFFFFFFu, is_signed, lds_slice, [&](const ParsedRun &r) {
-                if (mine && n_runs < STAGED_RUNS) {
-                    held[n_runs & (SB_HELD - 1)] = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes);
-                    if ((n_runs & (SB_HELD - 1)) == SB_HELD - 1) {
-                        u64x2 *dst = (u64x2 *)(mine + (n_runs - (SB_HELD - 1)));
-#pragma unroll
-                        for (uint32_t i = 0; i < SB_HELD / 2; i++) {
-                            u64x2 v;
-                            v.x = held[2 * i];
-                            v.y = held[2 * i + 1];
-                            dst[i] = v;
-                        }
-                    }
-                }
+                keep.put(n_runs, make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes));
                 n_runs++;
                 n_vals += r.len;
                 last_len = r.len;
             });
-            if (mine && n_runs < STAGED_RUNS)
-                for (uint32_t k = n_runs & ~(SB_HELD - 1); k < n_runs; k++) mine[k] = held[k & (SB_HELD - 1)];
+            keep.finish(n_runs);
         }
         if (status == SEG_OK && pos != end && !last_seg) status = SEG_MISALIGNED;
         seg_publish(t, seg, n_seg, n_runs, last_len, status, n_vals);
@@ -406,18 +388,20 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
     }
 }
 
-// EMIT for the segments whose descriptors the counting pass staged: one wavefront per segment, one
-// lane per run.  Nothing here waits on the header chain: a run's place follows from a wave scan of
+// EMIT for the segments whose descriptors the counting pass staged: a group of lanes per segment,
+// one lane per run.  Nothing here waits on the header chain: a run's place follows from a wave scan of
 // the lengths, and the base / second field of a window's first run from parsing that one header.
 __global__ __launch_bounds__(256) void rlev2_emit_staged_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
     const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
     const uint64_t *__restrict__ staged, uint64_t *__restrict__ runs,
     uint32_t *__restrict__ group_first, RunEntry *__restrict__ group_run, uint32_t n_group_slots,
-    int full_table) {
+    int full_table, uint32_t group) {
     static_assert(STAGED_RUNS == 64, "one lane per staged run");
-    const uint32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
+    // `group` lanes per segment (a power of two from 8 to 64, no less than the most runs any
+    // staged segment holds): a wavefront takes 64 / group segments
+    const uint32_t seg = (blockIdx.x * 256 + threadIdx.x) / group;
+    const uint32_t lane = threadIdx.x & (group - 1);
     if (seg >= n_seg) return;
     // everything the wavefront needs from memory is asked for at once (a staged slot that was
     // never written holds whatever it held; it is not looked at)
@@ -434,11 +418,11 @@ __global__ __launch_bounds__(256) void rlev2_emit_staged_kernel(
     const uint64_t desc = live ? staged_word : 0;
     const uint32_t rlen = live ? desc_len(desc) : 0;
     uint32_t incl = rlen;  // inclusive scan of the lengths
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t u = __shfl_up(incl, d);
-        if (lane >= (uint32_t)d) incl += u;
+    for (uint32_t d = 1; d < group; d <<= 1) {
+        const uint32_t u = __shfl_up(incl, d, (int)group);
+        if (lane >= d) incl += u;
     }
-    uint32_t prev_len = __shfl_up(rlen, 1);
+    uint32_t prev_len = __shfl_up(rlen, 1, (int)group);
     if (lane == 0) prev_len = so.prev_len;
     const uint64_t out_off = so.val_off + (incl - rlen);
     const uint32_t run_idx = so.run_off + lane;
@@ -1303,11 +1287,12 @@ hipError_t launch_rlev2_emit_staged(hipStream_t st, const uint8_t *stream, uint6
                                     const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                                     int is_signed, const SegTable &t, const uint64_t *staged,
                                     uint64_t *runs, uint32_t *group_first, RunEntry *group_run,
-                                    uint32_t n_group_slots, bool full_table) {
-    const uint32_t blocks = (n_seg + 3) / 4;
+                                    uint32_t n_group_slots, bool full_table, uint32_t max_seg_runs) {
+    const uint32_t group = staged_group_lanes(max_seg_runs);
+    const uint32_t blocks = (uint32_t)(((uint64_t)n_seg * group + 255) / 256);
     rlev2_emit_staged_kernel<<<blocks, 256, 0, st>>>(stream, len, entries, seg_ends, n_seg, is_signed, t,
                                                      staged, runs, group_first, group_run, n_group_slots,
-                                                     full_table ? 1 : 0);
+                                                     full_table ? 1 : 0, group);
     return hipGetLastError();
 }
 

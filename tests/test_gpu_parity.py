@@ -278,6 +278,53 @@ def test_boolean_random(gpu, oracle, seed):
     assert rc == 0 and (raw == packed).all()
 
 
+def _byte_rle_run_starts(stream):
+    starts, pos = [], 0
+    while pos < len(stream):
+        starts.append(pos)
+        c = stream[pos]
+        pos += 2 if c < 128 else 1 + (256 - c)
+    return starts
+
+
+@pytest.mark.parametrize("tail_gap", [1, 64, 65, 300])
+def test_byte_rle_irregular_entry_points(gpu, oracle, tail_gap):
+    """Byte-RLE / boolean streams cut into many segments of very different sizes: those of up
+    to 64 runs are emitted from the words the counting pass kept, longer ones by a second walk."""
+    rng = np.random.default_rng(600 + tail_gap)
+    # short runs and short literals, so that there are thousands of them
+    pieces = []
+    for _ in range(5000):
+        if rng.random() < 0.5:
+            pieces.append(bytes([int(rng.integers(0, 256))]) * int(rng.integers(3, 20)))
+        else:
+            pieces.append(bytes(rng.integers(0, 256, size=int(rng.integers(1, 9)), dtype=np.uint8)))
+    data = b"".join(pieces)
+    stream = enc.byte_rle(data, max_literal=int(rng.integers(4, 20)))
+    starts = _byte_rle_run_starts(stream)
+    assert len(starts) > 3000
+    picks, k = [0], 0
+    while True:
+        k += int(rng.choice([1, 2, 5, 63, 64, 65, 130]))
+        if k >= len(starts) - tail_gap:
+            break
+        picks.append(k)
+    picks.append(len(starts) - tail_gap)
+    assert len(picks) >= 64
+    entries = np.array([starts[i] for i in picks], dtype=np.uint64)
+    want = np.frombuffer(data, dtype=np.uint8)
+    rc, raw = gpu.byte_rle(stream, want.size, entries)
+    assert rc == 0 and (raw == want).all()
+    bits = np.unpackbits(want).astype(bool)
+    for n in (bits.size, bits.size - 3, bits.size // 2 + 1, 1025):
+        rc, out, ones = gpu.boolean(stream, n, entries)
+        assert rc == 0 and (out == bits[:n]).all() and ones == int(bits[:n].sum())
+    rc, out, ones = gpu.boolean(stream, bits.size, np.append(entries, np.uint64(len(stream))))
+    assert rc == 0 and (out == bits).all()
+    rc, ref, _ = oracle.boolean(stream, bits.size)
+    assert rc == 0 and (ref == bits).all()
+
+
 def test_floats(gpu, oracle):
     rng = np.random.default_rng(3)
     raw = rng.integers(0, 256, size=8 * 1001, dtype=np.uint8).tobytes()  # NaN payloads included
