@@ -430,13 +430,15 @@ __global__ __launch_bounds__(256) void rlev2_emit_staged_kernel(
     const bool first = live && ((out_off == 0) || (((out_off - prev_len) >> WINDOW_SHIFT) != win));
     const bool single = first && ((out_off + rlen) >> WINDOW_SHIFT) != win;
     const bool is_tail = last_seg && lane + 1 == (n_runs ? n_runs : 1u);  // the lane that writes the sentinel
-    // the header again, for a window's first run (base, second field) and for the end of the
-    // stream's last run; a Direct run has neither field
+    // the header again: for the base and second field of a run that has a window to itself (a
+    // Direct run has neither; the runs of a shared window are parsed by the value kernel's lanes,
+    // which never look at these fields of the per-window copy) and for the end of the stream's
+    // last run
     ParsedRun r;
     r.base = 0;
     r.aux = 0;
     r.run_end = 0;
-    if (live && ((first && win < n_group_slots && desc_kind(desc) != KIND_DIRECT) || is_tail)) {
+    if (live && ((single && win < n_group_slots && desc_kind(desc) != KIND_DIRECT) || is_tail)) {
         const uint64_t pos = desc_payload(desc) - desc_header_bytes(desc);
         (void)parse_run(load_window(s, limit, pos), s, limit, pos, is_signed, r);  // parsed fine once already
     }
