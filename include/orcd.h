@@ -80,6 +80,10 @@ int orcd_ctx_destroy(orcd_ctx *ctx);
 int orcd_ctx_set_stream(orcd_ctx *ctx, void *hip_stream);
 /* Blocks until everything enqueued by this context has finished. */
 int orcd_ctx_synchronize(orcd_ctx *ctx);
+/* Gives the device memory the context keeps for its next column calls (released result arrays and
+ * temporaries of orcd_decode_column / orcd_decode_stripe) back to the runtime; waits for the
+ * context's queued work first.  Nothing else changes: the next call allocates afresh. */
+int orcd_ctx_release_cached(orcd_ctx *ctx);
 /* Duration in milliseconds of the GPU work of the most recent decode call on this context,
  * measured with HIP events on the context's stream (waits for that work).  Negative on error. */
 float orcd_ctx_last_elapsed_ms(orcd_ctx *ctx);

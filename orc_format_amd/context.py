@@ -77,6 +77,10 @@ class Context:
     def synchronize(self):
         check(self._lib.orcd_ctx_synchronize(self._h), self._h)
 
+    def release_cached(self):
+        """Returns the device memory kept for the next column calls to the runtime."""
+        check(self._lib.orcd_ctx_release_cached(self._h), self._h)
+
     def last_elapsed_ms(self):
         return float(self._lib.orcd_ctx_last_elapsed_ms(self._h))
 

@@ -417,6 +417,17 @@ int orcd_ctx_set_stream(orcd_ctx *c, void *hip_stream) {
     return ORCD_OK;
 }
 
+int orcd_ctx_release_cached(orcd_ctx *c) {
+    if (!c) return ORCD_INVALID_ARGUMENT;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // queued work may still use a released block
+    std::lock_guard<std::mutex> lock(c->cache_lock);
+    for (auto &kv : c->cache_free) (void)hipFree(kv.second);
+    c->cache_free.clear();
+    c->cache_held = 0;
+    return ORCD_OK;
+}
+
 int orcd_ctx_synchronize(orcd_ctx *c) {
     if (!c) return ORCD_INVALID_ARGUMENT;
     DeviceGuard g(c->device);

@@ -128,6 +128,41 @@ def test_decode_column_on_device(golden_dir):
         assert not cd.validity
 
 
+def test_released_blocks_are_reused_and_can_be_given_back(golden_dir):
+    """Device arrays go back to the context when released and serve its next calls; the same
+    columns decode to the same bytes whatever the history of the cache."""
+    import ctypes as C
+    from orc_format_amd import _native as N
+    from orc_format_amd import Context, read
+    from orc_format_amd.error import check
+    ctx = Context(0)
+    md = read.read_metadata(os.path.join(golden_dir, "mixed_compression.orc"))
+    footer = read.read_stripe_footer(md, 0)
+    columns = list(range(1, len(md.types)))
+    want = ctx.decode_stripe(md, 0, footer, columns)
+    lib = N.lib()
+    arr = (C.c_uint32 * len(columns))(*columns)
+    seen = set()
+    for rep in range(4):
+        cds = (N.ColumnData * len(columns))()
+        check(lib.orcd_decode_stripe(ctx.handle, md._h, 0, footer._h, arr, len(columns), N.OUT_DEVICE, cds), ctx.handle)
+        ptrs = {cd.values for cd in cds if cd.values}
+        if seen:
+            assert ptrs & seen, "no released block was handed out again"
+        seen |= ptrs
+        # release in another order every time
+        for cd in (cds if rep % 2 else list(cds)[::-1]):
+            lib.orcd_column_data_free(C.byref(cd))
+        if rep == 2:
+            ctx.release_cached()
+            seen = set()
+        got = ctx.decode_stripe(md, 0, footer, columns)
+        for g, w in zip(got, want):
+            for key in w:
+                if isinstance(w[key], np.ndarray):
+                    assert g[key].tobytes() == w[key].tobytes(), (rep, key)
+
+
 def test_decode_column_errors(golden_dir):
     from orc_format_amd import _native as N
     from orc_format_amd import default_context, read
