@@ -81,7 +81,33 @@ def main():
         assert (g["values"][g["validity"]] == np.array(w.drop_null().to_pylist())).all()
     t_col = best_of(lambda: gpu(False))
     t_stripe = best_of(lambda: gpu(True))
-    for name, t in (("pyarrow (host)", t_arrow), ("per column", t_col), ("per stripe", t_stripe)):
+
+    # stripes dealt to two host threads, each with a context (and stream) of its own: one
+    # stripe's read and copy overlap the other's decode
+    from concurrent.futures import ThreadPoolExecutor
+    ctxs = [ctx, Context(0)]
+
+    def one_stripe(args):
+        k, md, stripe = args
+        footer = read.read_stripe_footer(md, stripe)
+        columns = list(range(1, len(md.types)))
+        arr = (C.c_uint32 * len(columns))(*columns)
+        cds = (N.ColumnData * len(columns))()
+        check(lib.orcd_decode_stripe(ctxs[k].handle, md._h, stripe, footer._h, arr, len(columns),
+                                     N.OUT_DEVICE | N.CHECK_UTF8, cds), ctxs[k].handle)
+        for cd in cds:
+            lib.orcd_column_data_free(C.byref(cd))
+
+    def gpu_two():
+        md = read.read_metadata(path)
+        with ThreadPoolExecutor(2) as pool:
+            list(pool.map(one_stripe, [(s % 2, md, s) for s in range(len(md.stripes))]))
+        for c in ctxs:
+            c.synchronize()
+
+    t_two = best_of(gpu_two)
+    for name, t in (("pyarrow (host)", t_arrow), ("per column", t_col), ("per stripe", t_stripe),
+                    ("2 contexts", t_two)):
         print("%-15s %.1f ms  %.2f GB/s of file" % (name, t * 1e3, size / t / 1e9), flush=True)
 
 
