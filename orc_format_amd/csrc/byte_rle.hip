@@ -120,9 +120,10 @@ __global__ __launch_bounds__(256) void byte_rle_emit_staged_kernel(
     uint32_t *__restrict__ win_first, uint32_t n_win_slots, uint32_t group) {
     static_assert(STAGED_RUNS == 64, "one lane per staged run");
     // `group` lanes per segment (see rlev2_emit_staged_kernel)
-    const uint32_t seg = (blockIdx.x * 256 + threadIdx.x) / group;
+    const uint64_t seg64 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / group;
     const uint32_t lane = threadIdx.x & (group - 1);
-    if (seg >= n_seg) return;
+    if (seg64 >= n_seg) return;
+    const uint32_t seg = (uint32_t)seg64;
     // (a staged slot that was never written holds whatever it held; it is not looked at)
     const uint64_t staged_word = staged[(uint64_t)seg * STAGED_RUNS + lane];
     const uint32_t n_runs = t.seg_count[seg].n_runs;
@@ -456,8 +457,9 @@ hipError_t launch_byte_rle_emit_staged(hipStream_t st, uint32_t n_seg, const Seg
                                        const uint64_t *staged, ByteRun *runs, uint32_t *win_first,
                                        uint32_t n_win_slots, uint32_t max_seg_runs) {
     const uint32_t group = staged_group_lanes(max_seg_runs);
-    const uint32_t blocks = (uint32_t)(((uint64_t)n_seg * group + 255) / 256);
-    byte_rle_emit_staged_kernel<<<blocks, 256, 0, st>>>(n_seg, t, staged, runs, win_first, n_win_slots, group);
+    const uint64_t blocks = ((uint64_t)n_seg * group + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    byte_rle_emit_staged_kernel<<<(uint32_t)blocks, 256, 0, st>>>(n_seg, t, staged, runs, win_first, n_win_slots, group);
     return hipGetLastError();
 }
 

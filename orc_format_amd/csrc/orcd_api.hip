@@ -1417,10 +1417,19 @@ int load_region(orcd_ctx *c, orcd_file *file, uint64_t file_off, uint64_t len, u
     if (n_threads <= 1) {
         if (n_threads == 1) reader(0);
     } else {
+        // (a thread that cannot be started leaves its chunks unread: they are read here afterwards)
         std::vector<std::thread> pool;
-        for (int t = 1; t < n_threads; t++) pool.emplace_back(reader, t);
+        std::vector<int> not_started;
+        for (int t = 1; t < n_threads; t++) {
+            try {
+                pool.emplace_back(reader, t);
+            } catch (...) {
+                not_started.push_back(t);
+            }
+        }
         reader(0);
         for (auto &th : pool) th.join();
+        for (int t : not_started) reader(t);
     }
     if (status != ORCD_OK) {
         if (hip_status != (int)hipSuccess) c->last_hip = (hipError_t)hip_status.load();

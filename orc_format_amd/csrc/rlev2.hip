@@ -400,9 +400,10 @@ __global__ __launch_bounds__(256) void rlev2_emit_staged_kernel(
     static_assert(STAGED_RUNS == 64, "one lane per staged run");
     // `group` lanes per segment (a power of two from 8 to 64, no less than the most runs any
     // staged segment holds): a wavefront takes 64 / group segments
-    const uint32_t seg = (blockIdx.x * 256 + threadIdx.x) / group;
+    const uint64_t seg64 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / group;
     const uint32_t lane = threadIdx.x & (group - 1);
-    if (seg >= n_seg) return;
+    if (seg64 >= n_seg) return;
+    const uint32_t seg = (uint32_t)seg64;
     // everything the wavefront needs from memory is asked for at once (a staged slot that was
     // never written holds whatever it held; it is not looked at)
     const uint64_t staged_word = staged[(uint64_t)seg * STAGED_RUNS + lane];
@@ -1291,8 +1292,9 @@ hipError_t launch_rlev2_emit_staged(hipStream_t st, const uint8_t *stream, uint6
                                     uint64_t *runs, uint32_t *group_first, RunEntry *group_run,
                                     uint32_t n_group_slots, bool full_table, uint32_t max_seg_runs) {
     const uint32_t group = staged_group_lanes(max_seg_runs);
-    const uint32_t blocks = (uint32_t)(((uint64_t)n_seg * group + 255) / 256);
-    rlev2_emit_staged_kernel<<<blocks, 256, 0, st>>>(stream, len, entries, seg_ends, n_seg, is_signed, t,
+    const uint64_t blocks = ((uint64_t)n_seg * group + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    rlev2_emit_staged_kernel<<<(uint32_t)blocks, 256, 0, st>>>(stream, len, entries, seg_ends, n_seg, is_signed, t,
                                                      staged, runs, group_first, group_run, n_group_slots,
                                                      full_table ? 1 : 0, group);
     return hipGetLastError();
