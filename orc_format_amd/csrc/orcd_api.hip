@@ -44,7 +44,7 @@ enum Slot {
     N_SLOTS
 };
 
-constexpr int N_READERS = 4;  // threads that read a stripe's bytes, each through a pinned chunk of its own
+constexpr int N_READERS = 8;  // threads that read a stripe's bytes, each through a pinned chunk of its own
 constexpr int N_EVENTS = 5;  // start, after header count + scan, after emit, after values / offsets, after string bytes
 
 }  // namespace
@@ -59,8 +59,9 @@ struct orcd_ctx {
     size_t cap[N_SLOTS] = {};
     ScanTotals *h_totals = nullptr;  // pinned
     uint64_t *h_scalars = nullptr;   // pinned, 8 words
-    uint8_t *h_stage[N_READERS] = {};  // pinned chunks for whole-stripe reads, allocated on first use
+    uint8_t *h_stage[N_READERS] = {};  // pinned chunks for large host transfers, allocated on first use
     hipEvent_t ev_stage[N_READERS] = {};
+    bool stage_busy[N_READERS] = {};   // a copy out of the chunk was queued and not yet waited for
     // Result arrays and per-call temporaries of the column calls: released blocks are kept and
     // handed out again (see dev_alloc).
     std::mutex cache_lock;
@@ -107,6 +108,124 @@ int ensure(orcd_ctx *c, Slot s, size_t bytes, void **out) {
     return ORCD_OK;
 }
 
+// ---- large transfers between host and device ---------------------------------------------------
+// A single thread moves a few GB/s out of the page cache or between pageable buffers (and the
+// runtime's own staging of a pageable hipMemcpy is one such thread), far less than the link.
+// Here N_READERS threads take the chunks of a transfer in turn, each through a pinned chunk of
+// its own: host-side copies (or file reads) overlap each other and the DMA.
+constexpr size_t STAGE_CHUNK = 8u << 20;
+constexpr size_t THREADED_COPY_MIN = 32u << 20;  // below this a plain hipMemcpyAsync is used
+
+struct HostSource {       // where the bytes of a transfer to the device come from
+    orcd_file *file;      // a file region starting at file_off ...
+    uint64_t file_off;
+    const uint8_t *mem;   // ... or host memory
+};
+
+// one chunk-sized step of thread t: returns an ORCD status, hip errors in *hip
+template <typename Step>
+int run_chunked(orcd_ctx *c, uint64_t len, Step step) {
+    for (int i = 0; i < N_READERS; i++) {
+        if (!c->h_stage[i]) HIP_TRY(c, hipHostMalloc((void **)&c->h_stage[i], STAGE_CHUNK, hipHostMallocDefault));
+        if (!c->ev_stage[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+    }
+    const uint64_t n_chunks = (len + STAGE_CHUNK - 1) / STAGE_CHUNK;
+    const int n_threads = (int)std::min<uint64_t>(N_READERS, n_chunks);
+    std::atomic<int> status{ORCD_OK};
+    std::atomic<int> hip_status{(int)hipSuccess};
+    auto worker = [&](int t) {
+        if (hipSetDevice(c->device) != hipSuccess) {
+            status = ORCD_HIP_ERROR;
+            return;
+        }
+        for (uint64_t k = (uint64_t)t; k < n_chunks && status == ORCD_OK; k += (uint64_t)n_threads) {
+            const uint64_t pos = k * STAGE_CHUNK, n = std::min<uint64_t>(STAGE_CHUNK, len - pos);
+            hipError_t e = hipSuccess;
+            const int rc = step(t, pos, n, &e);
+            if (rc != ORCD_OK) {
+                if (e != hipSuccess) hip_status = (int)e;
+                status = rc;
+                return;
+            }
+        }
+    };
+    if (n_threads <= 1) {
+        if (n_threads == 1) worker(0);
+    } else {
+        // (a thread that cannot be started leaves its chunks undone: they are done here afterwards)
+        std::vector<std::thread> pool;
+        std::vector<int> not_started;
+        for (int t = 1; t < n_threads; t++) {
+            try {
+                pool.emplace_back(worker, t);
+            } catch (...) {
+                not_started.push_back(t);
+            }
+        }
+        worker(0);
+        for (auto &th : pool) th.join();
+        for (int t : not_started) worker(t);
+    }
+    if (status != ORCD_OK) {
+        if (hip_status != (int)hipSuccess) c->last_hip = (hipError_t)hip_status.load();
+        (void)hipStreamSynchronize(c->stream);  // queued copies still use the pinned chunks
+        for (int i = 0; i < N_READERS; i++) c->stage_busy[i] = false;
+        return status;
+    }
+    return ORCD_OK;
+}
+
+// src -> d_dst, queued on the context's stream (the copies may still be running on return)
+int chunked_to_device(orcd_ctx *c, const HostSource &src, uint64_t len, uint8_t *d_dst) {
+    return run_chunked(c, len, [&](int t, uint64_t pos, uint64_t n, hipError_t *e) -> int {
+        if (c->stage_busy[t]) {  // the chunk's last copy is done
+            *e = hipEventSynchronize(c->ev_stage[t]);
+            if (*e != hipSuccess) return ORCD_HIP_ERROR;
+            c->stage_busy[t] = false;
+        }
+        if (src.file) {
+            const int rc = orcd_file_read_at(src.file, src.file_off + pos, n, c->h_stage[t]);
+            if (rc != ORCD_OK) return rc;
+        } else {
+            memcpy(c->h_stage[t], src.mem + pos, n);
+        }
+        *e = hipMemcpyAsync(d_dst + pos, c->h_stage[t], n, hipMemcpyHostToDevice, c->stream);
+        if (*e == hipSuccess) *e = hipEventRecord(c->ev_stage[t], c->stream);
+        if (*e != hipSuccess) return ORCD_HIP_ERROR;
+        c->stage_busy[t] = true;
+        return ORCD_OK;
+    });
+}
+
+// d_src -> h_dst; everything queued on the stream before has finished and the bytes are in
+// h_dst on return
+int chunked_to_host(orcd_ctx *c, const uint8_t *d_src, uint64_t len, uint8_t *h_dst) {
+    return run_chunked(c, len, [&](int t, uint64_t pos, uint64_t n, hipError_t *e) -> int {
+        if (c->stage_busy[t]) {
+            *e = hipEventSynchronize(c->ev_stage[t]);
+            if (*e != hipSuccess) return ORCD_HIP_ERROR;
+            c->stage_busy[t] = false;
+        }
+        *e = hipMemcpyAsync(c->h_stage[t], d_src + pos, n, hipMemcpyDeviceToHost, c->stream);
+        if (*e == hipSuccess) *e = hipEventRecord(c->ev_stage[t], c->stream);
+        if (*e == hipSuccess) *e = hipEventSynchronize(c->ev_stage[t]);
+        if (*e != hipSuccess) return ORCD_HIP_ERROR;
+        memcpy(h_dst + pos, c->h_stage[t], n);
+        return ORCD_OK;
+    });
+}
+
+// Host memory that the runtime does not know as pinned: its hipMemcpy would be staged by one
+// thread of the runtime.
+bool is_pageable(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;
+    }
+    return a.type == hipMemoryTypeUnregistered;
+}
+
 // Device view of an input: the pointer itself, or a staged copy of host memory.
 int stage_in(orcd_ctx *c, Slot s, const void *p, size_t bytes, bool on_device, const void **dev) {
     if (on_device) {
@@ -115,7 +234,12 @@ int stage_in(orcd_ctx *c, Slot s, const void *p, size_t bytes, bool on_device, c
     }
     void *d;
     ORCD_TRY(ensure(c, s, bytes, &d));
-    if (bytes) HIP_TRY(c, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream));
+    if (bytes >= THREADED_COPY_MIN && is_pageable(p)) {
+        const HostSource src = {nullptr, 0, (const uint8_t *)p};
+        ORCD_TRY(chunked_to_device(c, src, bytes, (uint8_t *)d));
+    } else if (bytes) {
+        HIP_TRY(c, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream));
+    }
     *dev = d;
     return ORCD_OK;
 }
@@ -330,7 +454,11 @@ int byte_rle_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
 }
 
 int copy_out(orcd_ctx *c, void *host, const void *dev, size_t bytes) {
-    if (bytes) HIP_TRY(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (bytes >= THREADED_COPY_MIN && is_pageable(host)) {
+        ORCD_TRY(chunked_to_host(c, (const uint8_t *)dev, bytes, (uint8_t *)host));
+    } else if (bytes) {
+        HIP_TRY(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ORCD_OK;
 }
@@ -1370,74 +1498,9 @@ struct StripeJob {
     explicit StripeJob(orcd_ctx *c) : p(c) {}
 };
 
-constexpr size_t STAGE_CHUNK = 8u << 20;
 // Streams up to this size share one set of launches -- and one wait for the header totals -- with
 // their peers (measured on a 26-column file: the larger the limit, the faster, up to here).
 constexpr uint64_t BATCH_STREAM_MAX = 64u << 20;
-
-// File bytes [file_off, file_off + len) -> d_dst.  A single thread reading from the page cache
-// moves a few GB/s, far less than the host-to-device link: N_READERS threads take the chunks in
-// turn, each reading into a pinned chunk of its own and queueing that chunk's copy, so reads
-// overlap each other and the copies.
-int load_region(orcd_ctx *c, orcd_file *file, uint64_t file_off, uint64_t len, uint8_t *d_dst) {
-    for (int i = 0; i < N_READERS; i++) {
-        if (!c->h_stage[i]) HIP_TRY(c, hipHostMalloc((void **)&c->h_stage[i], STAGE_CHUNK, hipHostMallocDefault));
-        if (!c->ev_stage[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
-    }
-    const uint64_t n_chunks = (len + STAGE_CHUNK - 1) / STAGE_CHUNK;
-    const int n_threads = (int)std::min<uint64_t>(N_READERS, n_chunks);
-    std::atomic<int> status{ORCD_OK};
-    std::atomic<int> hip_status{(int)hipSuccess};
-    auto reader = [&](int t) {
-        if (hipSetDevice(c->device) != hipSuccess) {
-            status = ORCD_HIP_ERROR;
-            return;
-        }
-        bool used = false;
-        for (uint64_t k = (uint64_t)t; k < n_chunks && status == ORCD_OK; k += (uint64_t)n_threads) {
-            const uint64_t pos = k * STAGE_CHUNK, n = std::min<uint64_t>(STAGE_CHUNK, len - pos);
-            hipError_t e = used ? hipEventSynchronize(c->ev_stage[t]) : hipSuccess;  // the chunk's last copy is done
-            if (e == hipSuccess) {
-                const int rc = orcd_file_read_at(file, file_off + pos, n, c->h_stage[t]);
-                if (rc != ORCD_OK) {
-                    status = rc;
-                    return;
-                }
-                e = hipMemcpyAsync(d_dst + pos, c->h_stage[t], n, hipMemcpyHostToDevice, c->stream);
-            }
-            if (e == hipSuccess) e = hipEventRecord(c->ev_stage[t], c->stream);
-            if (e != hipSuccess) {
-                hip_status = (int)e;
-                status = ORCD_HIP_ERROR;
-                return;
-            }
-            used = true;
-        }
-    };
-    if (n_threads <= 1) {
-        if (n_threads == 1) reader(0);
-    } else {
-        // (a thread that cannot be started leaves its chunks unread: they are read here afterwards)
-        std::vector<std::thread> pool;
-        std::vector<int> not_started;
-        for (int t = 1; t < n_threads; t++) {
-            try {
-                pool.emplace_back(reader, t);
-            } catch (...) {
-                not_started.push_back(t);
-            }
-        }
-        reader(0);
-        for (auto &th : pool) th.join();
-        for (int t : not_started) reader(t);
-    }
-    if (status != ORCD_OK) {
-        if (hip_status != (int)hipSuccess) c->last_hip = (hipError_t)hip_status.load();
-        (void)hipStreamSynchronize(c->stream);  // queued copies still read the pinned chunks
-        return status;
-    }
-    return ORCD_OK;
-}
 
 // One batch of streams that lie in the stripe's device copy: slice offsets are relative to the
 // first byte any of them uses.
@@ -1498,7 +1561,8 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     if (sb.lo > sb.hi) sb.lo = sb.hi = 0;
     ORCD_TRY(dev_alloc(c, sb.hi - sb.lo, &stripe_mem.tmp));
     sb.d_base = (const uint8_t *)stripe_mem.tmp;
-    ORCD_TRY(load_region(c, file, si.offset + sb.lo, sb.hi - sb.lo, (uint8_t *)stripe_mem.tmp));
+    const HostSource region = {file, si.offset + sb.lo, nullptr};
+    ORCD_TRY(chunked_to_device(c, region, sb.hi - sb.lo, (uint8_t *)stripe_mem.tmp));
 
     // 2. validity: the small PRESENT streams in one set of launches
     {

@@ -135,3 +135,30 @@ def test_long_streams_without_entry_points(oracle):
             assert rc_bad == 0 and torch.equal(out, torch.from_numpy(ref_bad).cuda()), name
         except OrcError:
             assert rc_bad != 0, name
+
+
+def test_large_pageable_host_buffers():
+    """Host buffers of tens of megabytes that are not pinned travel in chunks through pinned
+    staging on several threads, in both directions; the result is the same column.  A second call
+    (chunks still marked busy from the first) and a pinned input take the other ways through."""
+    import torch
+    from bench_util import synth
+    from orc_format_amd import default_context
+    ctx = default_context()
+    n_runs = 40_000                       # 43.6 MB of stream, 164 MB of values
+    stream, entries, values = synth.direct_w17(n_runs, seed=7, device="cuda")
+    n = n_runs * 512
+    want = values.cpu().numpy()
+    h_stream = stream.cpu().numpy().copy()
+    h_entries = entries.cpu().numpy().astype(np.uint64)
+    assert h_stream.nbytes >= 32 << 20
+    for _ in range(2):
+        out = ctx.rlev2(h_stream, n, True, h_entries)
+        assert (out == want).all()
+    # an odd length: the last chunk is partial and unaligned
+    cut = n - 512 * 3 - 1
+    out = ctx.rlev2(h_stream, cut, True, h_entries)
+    assert (out == want[:cut]).all()
+    pinned = torch.from_numpy(h_stream).pin_memory()
+    out = ctx.rlev2(pinned.numpy(), n, True, h_entries)
+    assert (out == want).all()
