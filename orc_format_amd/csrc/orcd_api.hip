@@ -463,6 +463,15 @@ int copy_out(orcd_ctx *c, void *host, const void *dev, size_t bytes) {
     return ORCD_OK;
 }
 
+// A result array to the caller's host buffer, without the final wait of copy_out (the large
+// pageable way waits by itself).
+int result_to_host(orcd_ctx *c, void *host, const void *dev, size_t bytes) {
+    if (bytes >= THREADED_COPY_MIN && is_pageable(host))
+        return chunked_to_host(c, (const uint8_t *)dev, bytes, (uint8_t *)host);
+    if (bytes) HIP_TRY(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    return ORCD_OK;
+}
+
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) {
@@ -909,8 +918,8 @@ int orcd_boolean_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t n
     if (d_count)
         HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_count, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     if (!out_dev) {
-        if (out_bytes) HIP_TRY(c, hipMemcpyAsync(out_bytes, d_bytes, num_bits, hipMemcpyDeviceToHost, c->stream));
-        if (out_bitmap) HIP_TRY(c, hipMemcpyAsync(out_bitmap, d_bitmap, n_bytes, hipMemcpyDeviceToHost, c->stream));
+        if (out_bytes) ORCD_TRY(result_to_host(c, out_bytes, d_bytes, num_bits));
+        if (out_bitmap) ORCD_TRY(result_to_host(c, out_bitmap, d_bitmap, n_bytes));
     }
     if (d_count || !out_dev) HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (set_bits) *set_bits = c->h_scalars[0];
@@ -1044,10 +1053,9 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
         }
     }
     if (!out_dev) {
-        HIP_TRY(c, hipMemcpyAsync(offsets, d_offsets, (num_values + 1) * sizeof(int64_t),
-                                  hipMemcpyDeviceToHost, c->stream));
+        ORCD_TRY(result_to_host(c, offsets, d_offsets, (num_values + 1) * sizeof(int64_t)));
         if (bytes_out && total)
-            HIP_TRY(c, hipMemcpyAsync(bytes_out, d_bytes, total, hipMemcpyDeviceToHost, c->stream));
+            ORCD_TRY(result_to_host(c, bytes_out, d_bytes, total));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return ORCD_OK;
@@ -1114,10 +1122,9 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
     }
     mark(c, 3);
     if (!out_dev) {
-        HIP_TRY(c, hipMemcpyAsync(offsets_out, d_offsets, (num_values + 1) * sizeof(int64_t),
-                                  hipMemcpyDeviceToHost, c->stream));
+        ORCD_TRY(result_to_host(c, offsets_out, d_offsets, (num_values + 1) * sizeof(int64_t)));
         if (bytes_out && total)
-            HIP_TRY(c, hipMemcpyAsync(bytes_out, d_bytes, total, hipMemcpyDeviceToHost, c->stream));
+            ORCD_TRY(result_to_host(c, bytes_out, d_bytes, total));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return ORCD_OK;
@@ -1274,13 +1281,12 @@ int deliver(orcd_ctx *c, void *d_ptr, size_t bytes, bool out_dev, void **result)
         dev_free(c, d_ptr);
         return ORCD_HIP_ERROR;
     }
-    hipError_t e = bytes ? hipMemcpyAsync(h, d_ptr, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    int rc = result_to_host(c, h, d_ptr, bytes);
+    if (rc == ORCD_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = ORCD_HIP_ERROR;
     dev_free(c, d_ptr);
-    if (e != hipSuccess) {
+    if (rc != ORCD_OK) {
         free(h);
-        c->last_hip = e;
-        return ORCD_HIP_ERROR;
+        return rc;
     }
     *result = h;
     return ORCD_OK;

@@ -162,3 +162,28 @@ def test_large_pageable_host_buffers():
     pinned = torch.from_numpy(h_stream).pin_memory()
     out = ctx.rlev2(pinned.numpy(), n, True, h_entries)
     assert (out == want).all()
+
+
+def test_large_pageable_results_of_other_decoders():
+    """The same chunked way back to the host for boolean values and string bytes."""
+    import torch
+    from bench_util import synth
+    from orc_format_amd import default_context
+    ctx = default_context()
+    # 41 M boolean values: 41 MB of one-byte values go back
+    stream, entries, decoded = synth.byte_rle_mix(40_000, seed=3, device="cuda")
+    bits = synth.unpack_bools(decoded, decoded.numel() * 8).cpu().numpy().astype(bool)
+    assert bits.size >= 32 << 20
+    out, ones = ctx.boolean(stream.cpu().numpy(), bits.size, entries.cpu().numpy().astype(np.uint64))
+    assert (out == bits).all() and ones == int(bits.sum())
+    # 1.2 M strings, 39 MB of ASCII bytes in and out
+    n_runs = 2400
+    lstream, lentries, lengths = synth.string_lengths_w6(n_runs, seed=5, device="cuda")
+    n = n_runs * 512
+    total = int(lengths.sum())
+    assert total >= 32 << 20
+    data = torch.randint(32, 127, (total,), dtype=torch.uint8, device="cuda").cpu().numpy()
+    offsets, got = ctx.string_direct(lstream.cpu().numpy(), data, n, check_utf8=True,
+                                     length_entry_points=lentries.cpu().numpy().astype(np.uint64))
+    want_off = np.concatenate([[0], np.cumsum(lengths.view(-1).cpu().numpy())])
+    assert (offsets == want_off).all() and got.tobytes() == data.tobytes()
