@@ -55,3 +55,24 @@ def sum_over_ranks(value, dist=None, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def decode_file_shard(ctx, metadata, rank, world_size, columns=None, row_aligned=True,
+                      check_utf8=True):
+    """The stripes of an open file that fall to `rank`, decoded on that rank's context (one
+    orcd_decode_stripe call per stripe).  Returns a list of (stripe index, first row of the stripe
+    in the file, [column dicts as Context.decode_stripe returns them]); the ranks' lists together
+    hold every stripe once, and the first rows say where each piece belongs -- no exchange is
+    needed to assemble the table (reference: the stripe loop of tests/it/main.rs:8-24, which this
+    spreads over ranks)."""
+    from . import read
+    if columns is None:
+        columns = list(range(1, len(metadata.types)))
+    first_rows = row_offsets([s.number_of_rows for s in metadata.stripes])
+    out = []
+    for stripe in stripes_of_rank(metadata, rank, world_size):
+        footer = read.read_stripe_footer(metadata, stripe)
+        out.append((stripe, first_rows[stripe],
+                    ctx.decode_stripe(metadata, stripe, footer, columns, check_utf8=check_utf8,
+                                      row_aligned=row_aligned)))
+    return out

@@ -252,3 +252,43 @@ def test_scatter_valid(dtype):
             with pytest.raises(OrcError) as ei:
                 ctx.scatter_valid(validity, dense[:-1])
             assert ei.value.code == N.INVALID_ARGUMENT
+
+
+def test_file_sharded_over_ranks_equals_pyarrow(tmp_path):
+    """A multi-stripe file decoded as two ranks would (each its own stripes, pieces placed by
+    their first row) is the table pyarrow reads."""
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    from orc_format_amd import default_context, read, shard
+    rng = np.random.default_rng(5)
+    rows = 300_000
+    table = pa.table({
+        "a": pa.array(rng.integers(-2**40, 2**40, size=rows), mask=rng.random(rows) < 0.2),
+        "b": pa.array(np.cumsum(rng.integers(1, 50, size=rows))),
+        "s": pa.array(["v%d" % k for k in rng.integers(0, 1000, size=rows)]),
+    })
+    path = str(tmp_path / "multi.orc")
+    orc.write_table(table, path, compression="uncompressed", stripe_size=1 << 20)
+    md = read.read_metadata(path)
+    assert len(md.stripes) >= 3
+    ctx = default_context()
+    a = np.zeros(rows, dtype=np.int64)
+    a_valid = np.zeros(rows, dtype=bool)
+    b = np.zeros(rows, dtype=np.int64)
+    s = [None] * rows
+    seen = []
+    for rank in range(2):
+        for stripe, first, cols in shard.decode_file_shard(ctx, md, rank, 2):
+            seen.append(stripe)
+            n = cols[0]["validity"].size
+            a[first:first + n] = cols[0]["values"]
+            a_valid[first:first + n] = cols[0]["validity"]
+            b[first:first + n] = cols[1]["values"]
+            off, raw = cols[2]["offsets"], cols[2]["bytes"].tobytes()
+            s[first:first + n] = [raw[off[i]:off[i + 1]].decode() for i in range(n)]
+    assert sorted(seen) == list(range(len(md.stripes)))
+    want = orc.ORCFile(path).read()
+    assert a_valid.tolist() == want.column("a").is_valid().to_pylist()
+    assert (a[a_valid] == np.array(want.column("a").drop_null().to_pylist())).all()
+    assert (b == np.array(want.column("b").to_pylist())).all()
+    assert s == want.column("s").to_pylist()
