@@ -243,6 +243,168 @@ __global__ __launch_bounds__(256) void byte_rle_expand_kernel(
     }
 }
 
+// Bytes, tile by tile: a wavefront takes BX_TILE decoded bytes; lane i of step j owns the 16
+// bytes at 1024*j + 16*i of the tile, so every store instruction writes 1 KiB of consecutive
+// output.  The runs that overlap the tile (at most 64, one per lane) go into a small LDS table,
+// the stream bytes they span -- one contiguous stretch -- into LDS with 16-byte loads; each lane
+// then finds the run of its first byte by binary search in the table and assembles its four
+// dwords from LDS: a dword inside one run is an unaligned LDS dword (literals) or a replicated
+// byte (run), a dword across two runs is a byte-wise mix of the two, anything finer goes byte by
+// byte.  Tiles with more runs or a longer stretch than fit fall back to per-lane walks.
+constexpr uint32_t BX_STEPS = 4;
+constexpr uint32_t BX_TILE = 1024 * BX_STEPS;
+constexpr uint32_t BX_RUNS = 64;
+constexpr uint32_t BX_SPAN = BX_RUNS * 132;  // stream bytes of 64 runs, control bytes between them included
+constexpr uint32_t BX_PAD = 16;              // LDS bytes in front of the stretch (never loaded, never used)
+
+struct __attribute__((aligned(16))) BxWave {
+    uint32_t bytes[(BX_PAD + BX_SPAN + 32) / 4 + 2];
+    int32_t rel[BX_RUNS + 2];    // start of run k relative to the tile; INT_MAX past the last
+    uint32_t srel[BX_RUNS + 2];  // its source relative to the first run's; bit 31: a run, not literals
+};
+
+struct BxCursor {  // runs k and k + 1 of the tile's table, and where k + 2 starts
+    const BxWave &L;
+    uint32_t base;  // LDS byte index of the first run's source
+    uint32_t k;
+    int32_t relA, relB, relC;
+    uint32_t srelA, srelB;
+    __device__ __forceinline__ void load(uint32_t k_) {
+        k = k_;
+        relA = L.rel[k];
+        srelA = L.srel[k];
+        relB = L.rel[k + 1];
+        srelB = L.srel[k + 1];
+        relC = k + 2 <= BX_RUNS + 1 ? L.rel[k + 2] : 0x7FFFFFFF;
+    }
+    __device__ __forceinline__ void advance() {
+        if (k + 1 > BX_RUNS) return;  // (sentinels keep q below relB before this can happen)
+        load(k + 1);
+    }
+    // the 4 decoded bytes at tile position q as if all of them belonged to the run (rel, srel)
+    __device__ __forceinline__ uint32_t dword_of(int32_t rel, uint32_t srel, int32_t q) const {
+        const uint32_t off = srel & 0x7FFFFFFFu;
+        if (srel >> 31) {
+            const uint32_t a = base + off;
+            return ((L.bytes[a >> 2] >> (8 * (a & 3))) & 0xFFu) * 0x01010101u;
+        }
+        const uint32_t a = base + off + (uint32_t)(q - rel);  // q - rel >= -3, base >= BX_PAD
+        return __builtin_amdgcn_alignbyte(L.bytes[(a >> 2) + 1], L.bytes[a >> 2], a & 3);
+    }
+    __device__ __forceinline__ uint32_t dword_at(int32_t q) {
+        while (q >= relB) advance();
+        if (q + 4 <= relB) return dword_of(relA, srelA, q);
+        if (q + 4 <= relC) {  // bytes below relB from run k, the rest from run k + 1
+            const uint32_t keep = 0xFFFFFFFFu >> (8 * (4 - (uint32_t)(relB - q)));
+            return (dword_of(relA, srelA, q) & keep) | (dword_of(relB, srelB, q) & ~keep);
+        }
+        uint32_t w = 0;
+        for (int32_t j = 0; j < 4; j++) {
+            while (q + j >= relB) advance();
+            w |= (dword_of(relA, srelA, q + j) & 0xFFu) << (8 * j);
+        }
+        return w;
+    }
+};
+
+__global__ __launch_bounds__(256) void byte_rle_tile_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const ByteRun *__restrict__ runs,
+    const uint32_t *__restrict__ win_first, uint32_t n_win_slots, uint32_t n_runs,
+    uint64_t num_bytes, uint8_t *__restrict__ out) {
+    __shared__ BxWave lds[4];
+    BxWave &L = lds[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t n_tiles = (num_bytes + BX_TILE - 1) / BX_TILE;
+    for (uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles;
+         tile += (uint64_t)gridDim.x * 4) {
+        const uint64_t tile_base = tile * BX_TILE;
+        // runs [r_lo, r_hi) overlap the tile (see bool_expand_kernel)
+        const uint64_t w0 = tile_base >> BR_WINDOW_SHIFT;
+        const uint64_t w1 = (w0 + BX_TILE / BR_WINDOW < n_win_slots) ? w0 + BX_TILE / BR_WINDOW : n_win_slots - 1;
+        uint32_t r_lo = __builtin_amdgcn_readfirstlane(win_first[w0]);
+        uint32_t r_hi = __builtin_amdgcn_readfirstlane(win_first[w1]);
+        if (r_hi > n_runs) r_hi = n_runs;
+        r_lo = r_lo > 0 ? r_lo - 1 : 0;
+        if (r_lo > r_hi) r_lo = r_hi;
+        const uint32_t nr = r_hi - r_lo;
+        bool fast = nr >= 1 && nr <= BX_RUNS;
+        int32_t my_rel = 0x7FFFFFFF;
+        uint64_t my_src = 0;
+        uint64_t src0 = 0, span = 0;
+        if (fast) {
+            if (lane < nr) {
+                const ByteRun run = runs[r_lo + lane];
+                my_rel = (int32_t)(int64_t)(run.out_off - tile_base);
+                my_src = run.src;
+            }
+            src0 = readfirst_u64(my_src) & PAYLOAD_MASK;
+            const uint64_t last = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_src >> 32), (int)nr - 1) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_src, (int)nr - 1);
+            const uint64_t end = (last & PAYLOAD_MASK) + ((last & BR_IS_RUN) ? 1 : ((last >> 40) & 0xFF) + 1);
+            span = end - src0;
+            // the first run of the tile must begin at or before it, and the stretch must fit
+            fast = end > src0 && span <= BX_SPAN && end <= len && __builtin_amdgcn_readfirstlane(my_rel) <= 0;
+        }
+        if (fast) {
+            const uint8_t *sb = s + src0;
+            const uint32_t skew = (uint32_t)((uintptr_t)sb & 15);
+            const uint4 *src16 = (const uint4 *)(sb - skew);  // aligned chunks that each hold a byte of the stretch
+            const uint32_t n16 = (uint32_t)((span + skew + 15) >> 4);
+            uint4 *dst16 = (uint4 *)(L.bytes + BX_PAD / 4);
+            for (uint32_t c = lane; c < n16; c += 64) dst16[c] = src16[c];
+            L.rel[lane] = my_rel;
+            L.srel[lane] = (uint32_t)((my_src & PAYLOAD_MASK) - src0) | ((my_src & BR_IS_RUN) ? 0x80000000u : 0u);
+            if (lane < 2) {
+                L.rel[BX_RUNS + lane] = 0x7FFFFFFF;
+                L.srel[BX_RUNS + lane] = 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            BxCursor cur = {L, BX_PAD + skew, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+            for (uint32_t step = 0; step < BX_STEPS; step++) {
+                const int32_t p = (int32_t)(1024 * step + 16 * lane);
+                const uint64_t o = tile_base + (uint32_t)p;
+                if (o >= num_bytes) continue;
+                // largest k with rel[k] <= p (rel[0] <= 0; entries past the last run hold INT_MAX)
+                uint32_t k = 0;
+#pragma unroll
+                for (uint32_t sft = 32; sft >= 1; sft >>= 1)
+                    if (L.rel[k + sft] <= p) k += sft;
+                cur.load(k);
+                uint32_t d[4];
+#pragma unroll
+                for (int32_t i = 0; i < 4; i++) d[i] = cur.dword_at(p + 4 * i);
+                uint8_t *dst = out + o;
+                if (o + 16 <= num_bytes) {
+                    *(uint4 *)dst = make_uint4(d[0], d[1], d[2], d[3]);
+                } else {
+                    for (uint32_t j = 0; j < 16 && o + j < num_bytes; j++) dst[j] = (uint8_t)(d[j >> 2] >> (8 * (j & 3)));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the next tile's LDS writes come after these reads
+        } else {
+            RunCursor cur = {s, len, runs, n_runs, 0, {0, 0}, 0, 0};
+            for (uint32_t step = 0; step < BX_STEPS; step++) {
+                const uint64_t o = tile_base + 1024 * step + 16 * lane;
+                if (o >= num_bytes) continue;
+                cur.find(win_first, o);
+                uint32_t d[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++)
+                    if (o + j < num_bytes) d[j >> 2] |= cur.byte_at(o + j) << (8 * (j & 3));
+                uint8_t *dst = out + o;
+                if (o + 16 <= num_bytes) {
+                    *(uint4 *)dst = make_uint4(d[0], d[1], d[2], d[3]);
+                } else {
+                    for (uint32_t j = 0; j < 16 && o + j < num_bytes; j++) dst[j] = (uint8_t)(d[j >> 2] >> (8 * (j & 3)));
+                }
+            }
+        }
+    }
+}
+
 // Stream byte at offset src (src < len), fetched as the aligned dword around it.
 __device__ __forceinline__ uint32_t stream_byte(const uint8_t *s, uint64_t src, uintptr_t &word_addr,
                                                 uint32_t &word) {
@@ -505,9 +667,15 @@ hipError_t launch_count_nonzero_slices(hipStream_t st, const uint8_t *bytes, con
 }
 
 hipError_t launch_byte_rle_expand(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                  const ByteRun *runs, const uint32_t *win_first, uint32_t n_runs,
-                                  uint64_t num_bytes, uint8_t *out) {
+                                  const ByteRun *runs, const uint32_t *win_first, uint32_t n_win_slots,
+                                  uint32_t n_runs, uint64_t num_bytes, uint8_t *out) {
     if (num_bytes == 0) return hipSuccess;
+    if ((((uintptr_t)out) & 15) == 0 && n_win_slots > 0) {
+        const uint64_t tiles = (num_bytes + BX_TILE - 1) / BX_TILE;  // one per wavefront, four per workgroup
+        byte_rle_tile_kernel<<<(uint32_t)std::min<uint64_t>((tiles + 3) / 4, BR_MAX_BLOCKS), 256, 0, st>>>(
+            stream, len, runs, win_first, n_win_slots, n_runs, num_bytes, out);
+        return hipGetLastError();
+    }
     const uint64_t lanes = (num_bytes + 15) / 16;
     byte_rle_expand_kernel<<<(uint32_t)std::min<uint64_t>((lanes + 255) / 256, BR_MAX_BLOCKS), 256, 0, st>>>(
         stream, len, runs, win_first, n_runs, num_bytes, out);

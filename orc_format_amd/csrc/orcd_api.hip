@@ -447,7 +447,7 @@ int byte_rle_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
                     const uint64_t *d_entries, size_t n_entries, uint8_t *d_out) {
     ByteRleTable t;
     ORCD_TRY(byte_rle_table(c, d_stream, len, num_bytes, d_entries, n_entries, &t));
-    HIP_TRY(c, launch_byte_rle_expand(c->stream, d_stream, len, t.runs, t.win_first, t.n_runs,
+    HIP_TRY(c, launch_byte_rle_expand(c->stream, d_stream, len, t.runs, t.win_first, t.n_win_slots, t.n_runs,
                                       num_bytes, d_out));
     mark(c, 3);
     return ORCD_OK;

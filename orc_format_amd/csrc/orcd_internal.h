@@ -177,8 +177,8 @@ hipError_t launch_count_nonzero_slices(hipStream_t st, const uint8_t *bytes, con
 // slots of win_first for a stream of total_bytes decoded bytes
 size_t byte_rle_window_slots(uint64_t total_bytes);
 hipError_t launch_byte_rle_expand(hipStream_t st, const uint8_t *stream, uint64_t len,
-                                  const ByteRun *runs, const uint32_t *win_first, uint32_t n_runs,
-                                  uint64_t num_bytes, uint8_t *out);
+                                  const ByteRun *runs, const uint32_t *win_first, uint32_t n_win_slots,
+                                  uint32_t n_runs, uint64_t num_bytes, uint8_t *out);
 // run table -> booleans in one pass: one byte per value, and/or an LSB-first bitmap, plus the
 // number of ones (set_bits must be zeroed beforehand)
 hipError_t launch_bool_expand(hipStream_t st, const uint8_t *stream, uint64_t len,

@@ -325,6 +325,68 @@ def test_byte_rle_irregular_entry_points(gpu, oracle, tail_gap):
     assert rc == 0 and (ref == bits).all()
 
 
+def _encode_pieces(pieces):
+    """pieces: ('r', byte, n) with 3 <= n <= 130 or ('l', bytes) with 1 <= len <= 128 -> stream, decoded."""
+    out, dec = bytearray(), bytearray()
+    for p in pieces:
+        if p[0] == "r":
+            out += bytes([p[2] - 3, p[1]])
+            dec += bytes([p[1]]) * p[2]
+        else:
+            out += bytes([256 - len(p[1])]) + p[1]
+            dec += p[1]
+    return bytes(out), bytes(dec)
+
+
+@pytest.mark.parametrize("shape", ["long", "tiny_between_long", "dense_tiny", "literals_only", "runs_only"])
+def test_byte_rle_tile_shapes(gpu, oracle, shape):
+    """Plain byte output over run shapes that take every way through the tiled expansion: dwords
+    inside one run, across two, across three and more (one- and two-byte literals between runs),
+    tiles with more than 64 runs (per-lane walk), odd totals."""
+    rng = np.random.default_rng(700 + ["long", "tiny_between_long", "dense_tiny", "literals_only", "runs_only"].index(shape))
+    pieces = []
+    for i in range(3000):
+        def lit(n):
+            return ("l", bytes(rng.integers(0, 256, size=n, dtype=np.uint8)))
+        def run(n):
+            return ("r", int(rng.integers(0, 256)), n)
+        if shape == "long":
+            pieces.append(run(int(rng.integers(100, 131))) if rng.random() < 0.5 else lit(int(rng.integers(90, 129))))
+        elif shape == "tiny_between_long":
+            pieces.append(run(130) if i % 2 else lit(128))
+            if rng.random() < 0.5:
+                pieces += [lit(int(rng.integers(1, 3))), run(3), lit(1)]
+        elif shape == "dense_tiny":
+            pieces.append(run(int(rng.integers(3, 6))) if rng.random() < 0.5 else lit(int(rng.integers(1, 4))))
+        elif shape == "literals_only":
+            pieces.append(lit(int(rng.integers(1, 129))))
+        else:
+            pieces.append(run(int(rng.integers(3, 131))))
+    stream, dec = _encode_pieces(pieces)
+    want = np.frombuffer(dec, dtype=np.uint8)
+    rc, ref = oracle.byte_rle(stream, want.size)
+    assert rc == 0 and (ref == want).all()
+    for n in (want.size, want.size - 1, want.size - 17, 4096, 4097, 15, 1):
+        rc, out = gpu.byte_rle(stream, n)
+        assert rc == 0 and (out == want[:n]).all(), n
+    # the stream at other 16-byte phases of device memory
+    import ctypes as C
+    import torch
+    from orc_format_amd import _native as N
+    from orc_format_amd import default_context
+    ctx = default_context()
+    for lead in (1, 5, 15):
+        d_stream = torch.zeros(lead + len(stream), dtype=torch.uint8, device="cuda")
+        d_stream[lead:] = torch.from_numpy(np.frombuffer(stream, np.uint8).copy())
+        d_out = torch.zeros(want.size, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        rc = N.lib().orcd_byte_rle_decode(ctx.handle, C.c_void_p(d_stream.data_ptr() + lead), len(stream),
+                                          want.size, None, 0, C.c_void_p(d_out.data_ptr()),
+                                          N.IN_DEVICE | N.OUT_DEVICE)
+        ctx.synchronize()
+        assert rc == 0 and (d_out.cpu().numpy() == want).all(), lead
+
+
 def test_floats(gpu, oracle):
     rng = np.random.default_rng(3)
     raw = rng.integers(0, 256, size=8 * 1001, dtype=np.uint8).tobytes()  # NaN payloads included
