@@ -34,6 +34,9 @@ WORKLOADS = {
     "mixed_short_runs": ("mixed_short_runs", {}, False,
                          "RLE v2 mix of ShortRepeat (3..10 copies) and Direct width 4 runs of 1..64 "
                          "values, unsigned, seed 44: every 512-value window holds about 25 runs"),
+    "mixed_short_runs_sparse": ("mixed_short_runs", {"runs_per_entry": 512}, False,
+                                "the same mix with an entry point every 512 runs (about every 10 000 "
+                                "values, the ROW_INDEX stride of a real file)"),
     # direct-encoded string column: LENGTH (unsigned RLE v2 Direct, width 6) + DATA
     "strings_w6": ("string_lengths_w6", {}, False,
                    "string column, lengths U[8,56] as RLE v2 Direct width 6 runs of 512 (seed 46), "
@@ -43,7 +46,8 @@ WORKLOADS = {
                     "boolean stream, byte-RLE mix of 128-byte literal groups (70%) and 130-byte runs "
                     "of 0xff (30%), seed 45; one byte per value + number of set bits"),
 }
-DEFAULT_ROWS = {"strings_w6": 250_000_000, "boolean_mix": 4_000_000_000, "mixed_short_runs": 500_000_000}
+DEFAULT_ROWS = {"strings_w6": 250_000_000, "boolean_mix": 4_000_000_000, "mixed_short_runs": 500_000_000,
+                "mixed_short_runs_sparse": 500_000_000}
 
 
 def main():
@@ -102,10 +106,10 @@ def main():
     seed = {"direct_w17": 42, "delta_monotonic": 43, "mixed_short_runs": 44}[gen_name] + 1000 * rank
     if gen_name == "mixed_short_runs":
         n_runs = max(1, args.rows // 20)     # a run holds 19.5 values on average
-        stream, entries, expect, entry_values = synth.mixed_short_runs(n_runs, seed=seed, device="cuda")
+        stream, entries, expect, entry_values = synth.mixed_short_runs(n_runs, seed=seed, device="cuda", **gen_kw)
         rows = int(expect.numel())
         cuts = (entry_values.cpu().numpy(), entries.cpu().numpy())
-        full_size = args.rows == DEFAULT_ROWS["mixed_short_runs"]
+        full_size = args.rows == DEFAULT_ROWS["mixed_short_runs"] and not gen_kw
     else:
         n_runs = max(1, args.rows // 512)
         rows = n_runs * 512

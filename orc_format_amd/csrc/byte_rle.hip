@@ -30,13 +30,13 @@ __global__ __launch_bounds__(SEG_BLOCK) void byte_rle_scan_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
     const uint64_t *__restrict__ seg_ends, uint32_t n_seg, SegTable t, ByteRun *__restrict__ runs,
     uint32_t *__restrict__ win_first, uint32_t n_win_slots, uint64_t *__restrict__ staged,
-    uint32_t staged_up_to) {
+    uint32_t staged_cap, uint32_t staged_up_to) {
     __shared__ uint64_t staged_words[EMIT ? 1 : SEG_BLOCK * SB_STRIDE];
     const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
     const bool valid = seg < n_seg;
     if (EMIT && !valid) return;
-    StagedWriter keep = {(!EMIT && staged && valid) ? staged + (uint64_t)seg * STAGED_RUNS : nullptr,
-                         staged_words + (EMIT ? 0 : threadIdx.x * SB_STRIDE)};
+    StagedWriter keep = {(!EMIT && staged && valid) ? staged + (uint64_t)seg * staged_cap : nullptr,
+                         staged_words + (EMIT ? 0 : threadIdx.x * SB_STRIDE), staged_cap};
     // seg_ends (nullable): the segments are slices of a larger buffer, each a stream of its own
     // that ends where it says (see the RLE v2 header scan)
     uint64_t pos = (valid && entries && (seg > 0 || seg_ends)) ? entries[seg] : 0;
@@ -114,60 +114,69 @@ __global__ __launch_bounds__(SEG_BLOCK) void byte_rle_scan_kernel(
 }
 
 // EMIT for the segments whose run words the counting pass staged: a group of lanes per segment,
-// one lane per run; a run's place in the output follows from a wave scan of the lengths.
+// one lane per run (a segment with more runs than lanes takes them a group at a time); a run's
+// place in the output follows from a scan of the lengths.
 __global__ __launch_bounds__(256) void byte_rle_emit_staged_kernel(
-    uint32_t n_seg, SegTable t, const uint64_t *__restrict__ staged, ByteRun *__restrict__ runs,
-    uint32_t *__restrict__ win_first, uint32_t n_win_slots, uint32_t group) {
-    static_assert(STAGED_RUNS == 64, "one lane per staged run");
+    uint32_t n_seg, SegTable t, const uint64_t *__restrict__ staged, uint32_t staged_cap,
+    ByteRun *__restrict__ runs, uint32_t *__restrict__ win_first, uint32_t n_win_slots, uint32_t group) {
     // `group` lanes per segment (see rlev2_emit_staged_kernel)
     const uint64_t seg64 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / group;
     const uint32_t lane = threadIdx.x & (group - 1);
     if (seg64 >= n_seg) return;
     const uint32_t seg = (uint32_t)seg64;
     // (a staged slot that was never written holds whatever it held; it is not looked at)
-    const uint64_t staged_word = staged[(uint64_t)seg * STAGED_RUNS + lane];
+    const uint64_t *mine = staged + (uint64_t)seg * staged_cap;
+    uint64_t staged_word = mine[lane];
     const uint32_t n_runs = t.seg_count[seg].n_runs;
     const SegOffset so = seg_global_offset(t, seg);
-    if (n_runs > STAGED_RUNS) return;  // the walking kernel emits this one
+    if (n_runs > staged_cap) return;  // the walking kernel emits this one
     const bool last_seg = seg + 1 == n_seg;
     if (n_runs == 0 && !last_seg) return;
-    const bool live = lane < n_runs;
-    const uint64_t src = live ? staged_word : 0;
-    const uint32_t n = live ? (uint32_t)((src >> 40) & 0xFF) + 1 : 0;
-    uint32_t incl = n;
-    for (uint32_t d = 1; d < group; d <<= 1) {
-        const uint32_t u = __shfl_up(incl, d, (int)group);
-        if (lane >= d) incl += u;
-    }
-    uint32_t prev_len = __shfl_up(n, 1, (int)group);
-    if (lane == 0) prev_len = so.prev_len;
-    const uint64_t out_off = so.val_off + (incl - n);
-    const uint32_t run_idx = so.run_off + lane;
-    if (live) {
-        ByteRun r;
-        r.src = src;
-        r.out_off = out_off;
-        runs[run_idx] = r;
-        // the same window rules as the walking kernel's
-        const uint64_t win = out_off >> BR_WINDOW_SHIFT;
-        const bool first = out_off == 0 || ((out_off - prev_len) >> BR_WINDOW_SHIFT) != win;
-        if (first && win < n_win_slots) win_first[win] = run_idx;
-        const uint64_t cov = win + 1;
-        if ((out_off & (BR_WINDOW - 1)) != 0 && ((cov + 1) << BR_WINDOW_SHIFT) <= out_off + n &&
-            cov < n_win_slots)
-            win_first[cov] = run_idx + 1;
-    }
-    if (last_seg && lane + 1 == (n_runs ? n_runs : 1u)) {
-        const uint64_t end_off = out_off + n;
-        const uint32_t end_prev = n_runs ? n : so.prev_len;
-        const uint32_t end_idx = so.run_off + n_runs;
-        ByteRun r;  // sentinel: an empty literal one past the end
-        r.src = 0;
-        r.out_off = end_off;
-        runs[end_idx] = r;
-        uint64_t w = end_off == 0 ? 0 : ((end_off - end_prev) >> BR_WINDOW_SHIFT) + 1;
-        const uint64_t w_end = (end_off + BR_WINDOW - 1) >> BR_WINDOW_SHIFT;
-        for (; w <= w_end && w < n_win_slots; w++) win_first[w] = end_idx;
+    uint64_t before = so.val_off;
+    uint32_t carry_prev = so.prev_len;
+    for (uint32_t base = 0; base == 0 || base < n_runs; base += group) {
+        if (base) staged_word = mine[base + lane];
+        const uint32_t k = base + lane;
+        const bool live = k < n_runs;
+        const uint64_t src = live ? staged_word : 0;
+        const uint32_t n = live ? (uint32_t)((src >> 40) & 0xFF) + 1 : 0;
+        uint32_t incl = n;
+        for (uint32_t d = 1; d < group; d <<= 1) {
+            const uint32_t u = __shfl_up(incl, d, (int)group);
+            if (lane >= d) incl += u;
+        }
+        uint32_t prev_len = __shfl_up(n, 1, (int)group);
+        if (lane == 0) prev_len = carry_prev;
+        const uint64_t out_off = before + (incl - n);
+        const uint32_t run_idx = so.run_off + k;
+        if (live) {
+            ByteRun r;
+            r.src = src;
+            r.out_off = out_off;
+            runs[run_idx] = r;
+            // the same window rules as the walking kernel's
+            const uint64_t win = out_off >> BR_WINDOW_SHIFT;
+            const bool first = out_off == 0 || ((out_off - prev_len) >> BR_WINDOW_SHIFT) != win;
+            if (first && win < n_win_slots) win_first[win] = run_idx;
+            const uint64_t cov = win + 1;
+            if ((out_off & (BR_WINDOW - 1)) != 0 && ((cov + 1) << BR_WINDOW_SHIFT) <= out_off + n &&
+                cov < n_win_slots)
+                win_first[cov] = run_idx + 1;
+        }
+        if (last_seg && k + 1 == (n_runs ? n_runs : 1u)) {
+            const uint64_t end_off = out_off + n;
+            const uint32_t end_prev = n_runs ? n : so.prev_len;
+            const uint32_t end_idx = so.run_off + n_runs;
+            ByteRun r;  // sentinel: an empty literal one past the end
+            r.src = 0;
+            r.out_off = end_off;
+            runs[end_idx] = r;
+            uint64_t w = end_off == 0 ? 0 : ((end_off - end_prev) >> BR_WINDOW_SHIFT) + 1;
+            const uint64_t w_end = (end_off + BR_WINDOW - 1) >> BR_WINDOW_SHIFT;
+            for (; w <= w_end && w < n_win_slots; w++) win_first[w] = end_idx;
+        }
+        before += __shfl(incl, (int)group - 1, (int)group);
+        carry_prev = __shfl(n, (int)group - 1, (int)group);
     }
 }
 
@@ -609,19 +618,19 @@ constexpr uint64_t BR_MAX_BLOCKS = 256 * 16;  // workgroups of the expansion: 16
 
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                                  const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
-                                 const SegTable &t, uint64_t *staged) {
+                                 const SegTable &t, uint64_t *staged, uint32_t staged_cap) {
     byte_rle_scan_kernel<false><<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(
-        stream, len, entries, seg_ends, n_seg, t, nullptr, nullptr, 0, staged, 0);
+        stream, len, entries, seg_ends, n_seg, t, nullptr, nullptr, 0, staged, staged_cap, 0);
     return hipGetLastError();
 }
 
 hipError_t launch_byte_rle_emit_staged(hipStream_t st, uint32_t n_seg, const SegTable &t,
-                                       const uint64_t *staged, ByteRun *runs, uint32_t *win_first,
-                                       uint32_t n_win_slots, uint32_t max_seg_runs) {
+                                       const uint64_t *staged, uint32_t staged_cap, ByteRun *runs,
+                                       uint32_t *win_first, uint32_t n_win_slots, uint32_t max_seg_runs) {
     const uint32_t group = staged_group_lanes(max_seg_runs);
     const uint64_t blocks = ((uint64_t)n_seg * group + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    byte_rle_emit_staged_kernel<<<(uint32_t)blocks, 256, 0, st>>>(n_seg, t, staged, runs, win_first, n_win_slots, group);
+    byte_rle_emit_staged_kernel<<<(uint32_t)blocks, 256, 0, st>>>(n_seg, t, staged, staged_cap, runs, win_first, n_win_slots, group);
     return hipGetLastError();
 }
 
@@ -630,7 +639,7 @@ hipError_t launch_byte_rle_emit(hipStream_t st, const uint8_t *stream, uint64_t 
                                 const SegTable &t, ByteRun *runs, uint32_t *win_first,
                                 uint32_t n_win_slots, uint32_t staged_up_to) {
     byte_rle_scan_kernel<true><<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(
-        stream, len, entries, seg_ends, n_seg, t, runs, win_first, n_win_slots, nullptr, staged_up_to);
+        stream, len, entries, seg_ends, n_seg, t, runs, win_first, n_win_slots, nullptr, 0, staged_up_to);
     return hipGetLastError();
 }
 

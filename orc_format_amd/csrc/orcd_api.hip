@@ -347,11 +347,12 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
     // With more than a few segments the counting pass keeps the descriptors it parses, and the
     // run table is then written without a second walk of the header chain.
     void *staged = nullptr;
-    if (n_seg >= 64) ORCD_TRY(ensure(c, SLOT_STAGED_RUNS, (size_t)n_seg * STAGED_RUNS * sizeof(uint64_t), &staged));
+    const uint32_t staged_cap = staged_runs_cap(len, n_seg);
+    if (n_seg >= 64) ORCD_TRY(ensure(c, SLOT_STAGED_RUNS, (size_t)n_seg * staged_cap * sizeof(uint64_t), &staged));
     ScanResult sr;
     ORCD_TRY(count_and_scan(c, n_seg, num_values, [&](const SegTable &st) {
         return launch_rlev2_count(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, st,
-                                  (uint64_t *)staged);
+                                  (uint64_t *)staged, staged_cap);
     }, &sr));
     mark(c, 1);
     if (seg_table) *seg_table = sr.table;
@@ -365,13 +366,13 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
     ORCD_TRY(ensure(c, SLOT_GROUP_RUNS, (size_t)n_slots * sizeof(RunEntry), &group_runs));
     if (staged)
         HIP_TRY(c, launch_rlev2_emit_staged(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed,
-                                            sr.table, (const uint64_t *)staged, (uint64_t *)runs,
+                                            sr.table, (const uint64_t *)staged, staged_cap, (uint64_t *)runs,
                                             (uint32_t *)groups, (RunEntry *)group_runs, (uint32_t)n_slots,
                                             full_table, sr.totals.max_seg_runs));
-    if (!staged || sr.totals.max_seg_runs > STAGED_RUNS)
+    if (!staged || sr.totals.max_seg_runs > staged_cap)
         HIP_TRY(c, launch_rlev2_emit(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, sr.table,
                                      (uint64_t *)runs, (uint32_t *)groups, (RunEntry *)group_runs,
-                                     (uint32_t)n_slots, full_table, staged ? STAGED_RUNS : 0));
+                                     (uint32_t)n_slots, full_table, staged ? staged_cap : 0));
     mark(c, 2);
     const uint64_t covered = std::min<uint64_t>(num_values, sr.totals.total_vals);
     t->stream = d_stream;
@@ -412,10 +413,12 @@ int byte_rle_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_
     const uint64_t *entries = n_entries ? d_entries : nullptr;
     const uint64_t *seg_ends = n_entries ? d_seg_ends : nullptr;
     void *staged = nullptr;  // as in rlev2_table
-    if (n_seg >= 64) ORCD_TRY(ensure(c, SLOT_STAGED_RUNS, (size_t)n_seg * STAGED_RUNS * sizeof(uint64_t), &staged));
+    const uint32_t staged_cap = staged_runs_cap(len, n_seg);
+    if (n_seg >= 64) ORCD_TRY(ensure(c, SLOT_STAGED_RUNS, (size_t)n_seg * staged_cap * sizeof(uint64_t), &staged));
     ScanResult sr;
     ORCD_TRY(count_and_scan(c, n_seg, num_bytes, [&](const SegTable &st) {
-        return launch_byte_rle_count(c->stream, d_stream, len, entries, seg_ends, n_seg, st, (uint64_t *)staged);
+        return launch_byte_rle_count(c->stream, d_stream, len, entries, seg_ends, n_seg, st, (uint64_t *)staged,
+                                     staged_cap);
     }, &sr));
     mark(c, 1);
     if (seg_table) *seg_table = sr.table;
@@ -427,13 +430,13 @@ int byte_rle_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_
     ORCD_TRY(ensure(c, SLOT_RUNS, (size_t)(sr.totals.total_runs + 1) * sizeof(ByteRun), &runs));
     ORCD_TRY(ensure(c, SLOT_GROUPS, n_slots * sizeof(uint32_t), &wins));
     if (staged)
-        HIP_TRY(c, launch_byte_rle_emit_staged(c->stream, n_seg, sr.table, (const uint64_t *)staged,
+        HIP_TRY(c, launch_byte_rle_emit_staged(c->stream, n_seg, sr.table, (const uint64_t *)staged, staged_cap,
                                                (ByteRun *)runs, (uint32_t *)wins, (uint32_t)n_slots,
                                                sr.totals.max_seg_runs));
-    if (!staged || sr.totals.max_seg_runs > STAGED_RUNS)
+    if (!staged || sr.totals.max_seg_runs > staged_cap)
         HIP_TRY(c, launch_byte_rle_emit(c->stream, d_stream, len, entries, seg_ends, n_seg, sr.table,
                                         (ByteRun *)runs, (uint32_t *)wins, (uint32_t)n_slots,
-                                        staged ? STAGED_RUNS : 0));
+                                        staged ? staged_cap : 0));
     mark(c, 2);
     t->runs = (const ByteRun *)runs;
     t->win_first = (const uint32_t *)wins;

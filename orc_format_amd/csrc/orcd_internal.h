@@ -105,14 +105,22 @@ struct SegTable;  // seg_scan.h
 
 // entries: start offset of every segment; seg_ends (nullable): its end, when the segments are
 // slices of a larger buffer rather than one gapless stream.
-// The counting pass keeps the descriptors of a segment's first STAGED_RUNS runs in
-// staged[seg * STAGED_RUNS + k] (nullable): segments that hold no more than that are then emitted
+// The counting pass keeps the descriptors of a segment's first `staged_cap` runs in
+// staged[seg * staged_cap + k] (nullable): segments that hold no more than that are then emitted
 // by launch_rlev2_emit_staged, one lane per run, without walking the header chain a second time;
 // launch_rlev2_emit walks the segments with more than `staged_up_to` runs (0: all of them).
-constexpr uint32_t STAGED_RUNS = 64;
+// staged_cap is chosen per stream from the bytes an average segment holds (staged_runs_cap): ROW_INDEX
+// positions come every 10 000 values, which is 20 runs of 512 values or 500 runs of 20.
+constexpr uint32_t STAGED_RUNS_MIN = 64, STAGED_RUNS_MAX = 512;
+inline uint32_t staged_runs_cap(uint64_t stream_len, uint32_t n_seg) {
+    const uint64_t avg = stream_len / (n_seg ? n_seg : 1);
+    uint32_t cap = STAGED_RUNS_MIN;
+    while (cap < STAGED_RUNS_MAX && (uint64_t)cap * 16 < avg) cap <<= 1;  // a run of 16 stream bytes on average
+    return cap;
+}
 hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                               const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
-                              int is_signed, const SegTable &t, uint64_t *staged);
+                              int is_signed, const SegTable &t, uint64_t *staged, uint32_t staged_cap);
 hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                              const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                              int is_signed, const SegTable &t, uint64_t *runs, uint32_t *group_first,
@@ -121,13 +129,14 @@ hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len
 hipError_t launch_rlev2_emit_staged(hipStream_t st, const uint8_t *stream, uint64_t len,
                                     const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                                     int is_signed, const SegTable &t, const uint64_t *staged,
-                                    uint64_t *runs, uint32_t *group_first, RunEntry *group_run,
-                                    uint32_t n_group_slots, bool full_table, uint32_t max_seg_runs);
+                                    uint32_t staged_cap, uint64_t *runs, uint32_t *group_first,
+                                    RunEntry *group_run, uint32_t n_group_slots, bool full_table,
+                                    uint32_t max_seg_runs);
 // lanes the staged emit kernels give a segment: the power of two from 8 to 64 that holds the
-// most runs any segment has (segments with more than STAGED_RUNS are not theirs)
+// most runs any segment has (a segment with more takes them 64 at a time)
 inline uint32_t staged_group_lanes(uint32_t max_seg_runs) {
     uint32_t g = 8;
-    while (g < STAGED_RUNS && g < max_seg_runs) g <<= 1;
+    while (g < 64 && g < max_seg_runs) g <<= 1;
     return g;
 }
 // Parallel check of a guessed header chain (see rlev2.hip): the size of the run at `pos`, and the
@@ -164,14 +173,14 @@ hipError_t launch_rlev2_offsets(hipStream_t st, const Rlev2Table &t, const uint6
 // (staged, staged_up_to: as for the RLE v2 passes; a staged word is the run's ByteRun::src)
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                                  const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
-                                 const SegTable &t, uint64_t *staged);
+                                 const SegTable &t, uint64_t *staged, uint32_t staged_cap);
 hipError_t launch_byte_rle_emit(hipStream_t st, const uint8_t *stream, uint64_t len,
                                 const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                                 const SegTable &t, ByteRun *runs, uint32_t *win_first,
                                 uint32_t n_win_slots, uint32_t staged_up_to);
 hipError_t launch_byte_rle_emit_staged(hipStream_t st, uint32_t n_seg, const SegTable &t,
-                                       const uint64_t *staged, ByteRun *runs, uint32_t *win_first,
-                                       uint32_t n_win_slots, uint32_t max_seg_runs);
+                                       const uint64_t *staged, uint32_t staged_cap, ByteRun *runs,
+                                       uint32_t *win_first, uint32_t n_win_slots, uint32_t max_seg_runs);
 hipError_t launch_count_nonzero_slices(hipStream_t st, const uint8_t *bytes, const uint64_t *start,
                                        const uint64_t *count, uint32_t n_slices, uint64_t *out);
 // slots of win_first for a stream of total_bytes decoded bytes

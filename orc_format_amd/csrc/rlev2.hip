@@ -299,7 +299,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
     const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
     uint64_t *__restrict__ runs, uint32_t *__restrict__ group_first,
     RunEntry *__restrict__ group_run, uint32_t n_group_slots, int full_table,
-    uint64_t *__restrict__ staged, uint32_t staged_up_to) {
+    uint64_t *__restrict__ staged, uint32_t staged_cap, uint32_t staged_up_to) {
     __shared__ uint64_t header_bytes[SEG_BLOCK * HB_STRIDE];
     __shared__ uint64_t staged_bytes[EMIT ? 1 : SEG_BLOCK * SB_STRIDE];
     uint64_t *lds_slice = header_bytes + threadIdx.x * HB_STRIDE;
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
         uint64_t n_vals = 0;
         if (end > len || end < pos) status = SEG_MISALIGNED;
         if (valid && status == SEG_OK) {
-            StagedWriter keep = {staged ? staged + (uint64_t)seg * STAGED_RUNS : nullptr,
-                                 staged_bytes + threadIdx.x * SB_STRIDE};
+            StagedWriter keep = {staged ? staged + (uint64_t)seg * staged_cap : nullptr,
+                                 staged_bytes + threadIdx.x * SB_STRIDE, staged_cap};
             status = walk_headers(s, limit, pos, end, 0xFFFFFFFFu, is_signed, lds_slice, [&](const ParsedRun &r) {
                 keep.put(n_runs, make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes));
                 n_runs++;
@@ -389,93 +389,109 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
 }
 
 // EMIT for the segments whose descriptors the counting pass staged: a group of lanes per segment,
-// one lane per run.  Nothing here waits on the header chain: a run's place follows from a wave scan of
-// the lengths, and the base / second field of a window's first run from parsing that one header.
+// one lane per run (a segment with more runs than lanes takes them a group at a time).  Nothing
+// here waits on the header chain: a run's place follows from a scan of the lengths, and the base /
+// second field of a run that has a window to itself from parsing that one header.
 __global__ __launch_bounds__(256) void rlev2_emit_staged_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
     const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
-    const uint64_t *__restrict__ staged, uint64_t *__restrict__ runs,
+    const uint64_t *__restrict__ staged, uint32_t staged_cap, uint64_t *__restrict__ runs,
     uint32_t *__restrict__ group_first, RunEntry *__restrict__ group_run, uint32_t n_group_slots,
     int full_table, uint32_t group) {
-    static_assert(STAGED_RUNS == 64, "one lane per staged run");
-    // `group` lanes per segment (a power of two from 8 to 64, no less than the most runs any
-    // staged segment holds): a wavefront takes 64 / group segments
+    // `group` lanes per segment (a power of two from 8 to 64): a wavefront takes 64 / group segments
     const uint64_t seg64 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / group;
     const uint32_t lane = threadIdx.x & (group - 1);
     if (seg64 >= n_seg) return;
     const uint32_t seg = (uint32_t)seg64;
-    // everything the wavefront needs from memory is asked for at once (a staged slot that was
+    // everything the group needs from memory first is asked for at once (a staged slot that was
     // never written holds whatever it held; it is not looked at)
-    const uint64_t staged_word = staged[(uint64_t)seg * STAGED_RUNS + lane];
+    const uint64_t *mine = staged + (uint64_t)seg * staged_cap;
+    uint64_t staged_word = mine[lane];  // staged_cap >= 64 >= group
     const uint32_t n_runs = t.seg_count[seg].n_runs;
     const SegOffset so = seg_global_offset(t, seg);
     const uint64_t seg_end = seg_ends ? seg_ends[seg] : len;
-    if (n_runs > STAGED_RUNS) return;  // the walking kernel emits this one
+    if (n_runs > staged_cap) return;  // the walking kernel emits this one
     const bool last_seg = seg + 1 == n_seg;
     if (n_runs == 0 && !last_seg) return;
     // the stream as this segment sees it (see rlev2_scan_kernel)
     const uint64_t limit = seg_end < len ? seg_end : len;
-    const bool live = lane < n_runs;
-    const uint64_t desc = live ? staged_word : 0;
-    const uint32_t rlen = live ? desc_len(desc) : 0;
-    uint32_t incl = rlen;  // inclusive scan of the lengths
-    for (uint32_t d = 1; d < group; d <<= 1) {
-        const uint32_t u = __shfl_up(incl, d, (int)group);
-        if (lane >= d) incl += u;
-    }
-    uint32_t prev_len = __shfl_up(rlen, 1, (int)group);
-    if (lane == 0) prev_len = so.prev_len;
-    const uint64_t out_off = so.val_off + (incl - rlen);
-    const uint32_t run_idx = so.run_off + lane;
-    const uint64_t win = out_off >> WINDOW_SHIFT;
-    const bool first = live && ((out_off == 0) || (((out_off - prev_len) >> WINDOW_SHIFT) != win));
-    const bool single = first && ((out_off + rlen) >> WINDOW_SHIFT) != win;
-    const bool is_tail = last_seg && lane + 1 == (n_runs ? n_runs : 1u);  // the lane that writes the sentinel
-    // the header again: for the base and second field of a run that has a window to itself (a
-    // Direct run has neither; the runs of a shared window are parsed by the value kernel's lanes,
-    // which never look at these fields of the per-window copy) and for the end of the stream's
-    // last run
-    ParsedRun r;
-    r.base = 0;
-    r.aux = 0;
-    r.run_end = 0;
-    if (live && ((single && win < n_group_slots && desc_kind(desc) != KIND_DIRECT) || is_tail)) {
-        const uint64_t pos = desc_payload(desc) - desc_header_bytes(desc);
-        (void)parse_run(load_window(s, limit, pos), s, limit, pos, is_signed, r);  // parsed fine once already
-    }
-    if (live && (!single || full_table)) runs[run_idx] = desc;
-    if (first && win < n_group_slots) {
-        group_first[win] = run_idx;
-        RunEntry ge;
-        ge.desc = single ? desc | DESC_SINGLE : desc;
-        ge.out_off = out_off;
-        ge.base = r.base;
-        ge.aux = r.aux;
-        group_run[win] = ge;
-    }
-    if (is_tail) {
-        // sentinel: one-past-the-end run and the windows after the last run start (see
-        // rlev2_scan_kernel)
-        uint64_t pos = r.run_end;
-        if (n_runs == 0) {
-            pos = (entries && (seg > 0 || seg_ends)) ? entries[seg] : 0;
-            if (pos > len) pos = len;
+    uint64_t before = so.val_off;        // values before the chunk's first run
+    uint32_t carry_prev = so.prev_len;   // length of the run before the chunk's first
+    auto chunk = [&](const uint32_t base) {
+        const uint32_t k = base + lane;
+        const bool live = k < n_runs;
+        const uint64_t desc = live ? staged_word : 0;
+        const uint32_t rlen = live ? desc_len(desc) : 0;
+        uint32_t incl = rlen;  // inclusive scan of the lengths
+        for (uint32_t d = 1; d < group; d <<= 1) {
+            const uint32_t u = __shfl_up(incl, d, (int)group);
+            if (lane >= d) incl += u;
         }
-        const uint64_t end_off = out_off + rlen;
-        const uint32_t end_prev = n_runs ? rlen : so.prev_len;
-        const uint32_t end_idx = so.run_off + n_runs;
-        RunEntry e;
-        e.desc = make_desc(pos, KIND_SHORT_REPEAT, 0, 1, 0, 1);
-        e.out_off = end_off;
-        e.base = 0;
-        e.aux = 0;
-        runs[end_idx] = e.desc;
-        const uint64_t g_end = (end_off + WINDOW - 1) >> WINDOW_SHIFT;
-        uint64_t g = end_off == 0 ? 0 : ((end_off - end_prev) >> WINDOW_SHIFT) + 1;
-        for (; g <= g_end && g < n_group_slots; g++) {
-            group_first[g] = end_idx;
-            group_run[g] = e;
+        uint32_t prev_len = __shfl_up(rlen, 1, (int)group);
+        if (lane == 0) prev_len = carry_prev;
+        const uint64_t out_off = before + (incl - rlen);
+        const uint32_t run_idx = so.run_off + k;
+        const uint64_t win = out_off >> WINDOW_SHIFT;
+        const bool first = live && ((out_off == 0) || (((out_off - prev_len) >> WINDOW_SHIFT) != win));
+        const bool single = first && ((out_off + rlen) >> WINDOW_SHIFT) != win;
+        const bool is_tail = last_seg && k + 1 == (n_runs ? n_runs : 1u);  // the lane that writes the sentinel
+        // the header again: for the base and second field of a run that has a window to itself (a
+        // Direct run has neither; the runs of a shared window are parsed by the value kernel's
+        // lanes, which never look at these fields of the per-window copy) and for the end of the
+        // stream's last run
+        ParsedRun r;
+        r.base = 0;
+        r.aux = 0;
+        r.run_end = 0;
+        if (live && ((single && win < n_group_slots && desc_kind(desc) != KIND_DIRECT) || is_tail)) {
+            const uint64_t pos = desc_payload(desc) - desc_header_bytes(desc);
+            (void)parse_run(load_window(s, limit, pos), s, limit, pos, is_signed, r);  // parsed fine once already
         }
+        if (live && (!single || full_table)) runs[run_idx] = desc;
+        if (first && win < n_group_slots) {
+            group_first[win] = run_idx;
+            RunEntry ge;
+            ge.desc = single ? desc | DESC_SINGLE : desc;
+            ge.out_off = out_off;
+            ge.base = r.base;
+            ge.aux = r.aux;
+            group_run[win] = ge;
+        }
+        if (is_tail) {
+            // sentinel: one-past-the-end run and the windows after the last run start (see
+            // rlev2_scan_kernel)
+            uint64_t pos = r.run_end;
+            if (n_runs == 0) {
+                pos = (entries && (seg > 0 || seg_ends)) ? entries[seg] : 0;
+                if (pos > len) pos = len;
+            }
+            const uint64_t end_off = out_off + rlen;
+            const uint32_t end_prev = n_runs ? rlen : so.prev_len;
+            const uint32_t end_idx = so.run_off + n_runs;
+            RunEntry e;
+            e.desc = make_desc(pos, KIND_SHORT_REPEAT, 0, 1, 0, 1);
+            e.out_off = end_off;
+            e.base = 0;
+            e.aux = 0;
+            runs[end_idx] = e.desc;
+            const uint64_t g_end = (end_off + WINDOW - 1) >> WINDOW_SHIFT;
+            uint64_t g = end_off == 0 ? 0 : ((end_off - end_prev) >> WINDOW_SHIFT) + 1;
+            for (; g <= g_end && g < n_group_slots; g++) {
+                group_first[g] = end_idx;
+                group_run[g] = e;
+            }
+        }
+        // on to the next chunk: totals of this one, from the group's last lane
+        if (n_runs > group) {
+            before += __shfl(incl, (int)group - 1, (int)group);
+            carry_prev = __shfl(rlen, (int)group - 1, (int)group);
+        }
+    };
+    chunk(0);
+    // a segment with more runs than the group has lanes: the rest, a group at a time
+    for (uint32_t base = group; base < n_runs; base += group) {
+        staged_word = mine[base + lane];  // base + lane < staged_cap (both multiples of group)
+        chunk(base);
     }
 }
 
@@ -1259,11 +1275,11 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
 
 hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                               const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
-                              int is_signed, const SegTable &t, uint64_t *staged) {
+                              int is_signed, const SegTable &t, uint64_t *staged, uint32_t staged_cap) {
     const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
     rlev2_scan_kernel<false><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, seg_ends, n_seg,
                                                           is_signed, t, nullptr, nullptr, nullptr, 0, 0,
-                                                          staged, 0);
+                                                          staged, staged_cap, 0);
     return hipGetLastError();
 }
 
@@ -1282,21 +1298,22 @@ hipError_t launch_rlev2_emit(hipStream_t st, const uint8_t *stream, uint64_t len
     rlev2_scan_kernel<true><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, seg_ends, n_seg,
                                                          is_signed, t, runs, group_first, group_run,
                                                          n_group_slots, full_table ? 1 : 0, nullptr,
-                                                         staged_up_to);
+                                                         0, staged_up_to);
     return hipGetLastError();
 }
 
 hipError_t launch_rlev2_emit_staged(hipStream_t st, const uint8_t *stream, uint64_t len,
                                     const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                                     int is_signed, const SegTable &t, const uint64_t *staged,
-                                    uint64_t *runs, uint32_t *group_first, RunEntry *group_run,
-                                    uint32_t n_group_slots, bool full_table, uint32_t max_seg_runs) {
+                                    uint32_t staged_cap, uint64_t *runs, uint32_t *group_first,
+                                    RunEntry *group_run, uint32_t n_group_slots, bool full_table,
+                                    uint32_t max_seg_runs) {
     const uint32_t group = staged_group_lanes(max_seg_runs);
     const uint64_t blocks = ((uint64_t)n_seg * group + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     rlev2_emit_staged_kernel<<<(uint32_t)blocks, 256, 0, st>>>(stream, len, entries, seg_ends, n_seg, is_signed, t,
-                                                     staged, runs, group_first, group_run, n_group_slots,
-                                                     full_table ? 1 : 0, group);
+                                                     staged, staged_cap, runs, group_first, group_run,
+                                                     n_group_slots, full_table ? 1 : 0, group);
     return hipGetLastError();
 }
 

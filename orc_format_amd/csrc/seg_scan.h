@@ -142,8 +142,8 @@ __device__ __forceinline__ SegOffset seg_global_offset(const SegTable &t, uint32
     return o;
 }
 
-// The counting pass keeps one 64-bit word per run for the first STAGED_RUNS runs of a segment in
-// staged[seg * STAGED_RUNS + k], so that the run table can be written later by one lane per run
+// The counting pass keeps one 64-bit word per run for the first `cap` runs of a segment in
+// staged[seg * cap + k] (cap: a multiple of SB_HELD chosen per call), so that the run table can be written later by one lane per run
 // instead of a second walk of the header chain.  The words leave in pieces of SB_HELD, collected
 // in a lane-private LDS stretch: all lanes of the grid write at once, each to a place of its own,
 // and 8-byte pieces of that many cache lines would each go out to memory as a partial line.
@@ -152,11 +152,12 @@ constexpr uint32_t SB_STRIDE = SB_HELD + 1;  // LDS pitch in words (odd: spreads
 typedef unsigned long long seg_u64x2 __attribute__((ext_vector_type(2)));
 
 struct StagedWriter {
-    uint64_t *mine;  // this segment's STAGED_RUNS slots, or null: nothing is staged
+    uint64_t *mine;  // this segment's `cap` slots, or null: nothing is staged
     uint64_t *held;  // this lane's SB_STRIDE words of LDS
+    uint32_t cap;
     // word of the segment's k-th run; k ascends by one from 0
     __device__ __forceinline__ void put(uint32_t k, uint64_t word) {
-        if (!mine || k >= STAGED_RUNS) return;
+        if (!mine || k >= cap) return;
         held[k & (SB_HELD - 1)] = word;
         if ((k & (SB_HELD - 1)) != SB_HELD - 1) return;
         seg_u64x2 *dst = (seg_u64x2 *)(mine + (k - (SB_HELD - 1)));
@@ -170,7 +171,7 @@ struct StagedWriter {
     }
     // after the last put: n runs were seen in all
     __device__ __forceinline__ void finish(uint32_t n) {
-        if (!mine || n >= STAGED_RUNS) return;  // a full table left with its last piece
+        if (!mine || n >= cap) return;  // a full table left with its last piece
         for (uint32_t k = n & ~(SB_HELD - 1); k < n; k++) mine[k] = held[k & (SB_HELD - 1)];
     }
 };

@@ -181,10 +181,10 @@ def test_irregular_entry_points(gpu, oracle, signed, tail_gap):
     """Many segments of very different sizes: those of up to 64 runs are emitted from the
     descriptors the counting pass kept, longer ones by a second walk, in one run table."""
     rng = np.random.default_rng(500 + tail_gap + signed)
-    stream, expect, starts = enc.random_stream(rng, 6000, signed, max_len=40)
+    stream, expect, starts = enc.random_stream(rng, 20000, signed, max_len=40)
     picks, k = [0], 0
     while True:
-        k += int(rng.choice([1, 2, 5, 63, 64, 65, 130]))
+        k += int(rng.choice([1, 2, 5, 63, 64, 65, 130, 300, 600]))
         if k >= len(starts) - tail_gap:
             break
         picks.append(k)
@@ -294,7 +294,7 @@ def test_byte_rle_irregular_entry_points(gpu, oracle, tail_gap):
     rng = np.random.default_rng(600 + tail_gap)
     # short runs and short literals, so that there are thousands of them
     pieces = []
-    for _ in range(5000):
+    for _ in range(20000):
         if rng.random() < 0.5:
             pieces.append(bytes([int(rng.integers(0, 256))]) * int(rng.integers(3, 20)))
         else:
@@ -305,7 +305,7 @@ def test_byte_rle_irregular_entry_points(gpu, oracle, tail_gap):
     assert len(starts) > 3000
     picks, k = [0], 0
     while True:
-        k += int(rng.choice([1, 2, 5, 63, 64, 65, 130]))
+        k += int(rng.choice([1, 2, 5, 63, 64, 65, 130, 300, 600]))
         if k >= len(starts) - tail_gap:
             break
         picks.append(k)
