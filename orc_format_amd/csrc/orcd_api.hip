@@ -1120,7 +1120,7 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
             d_bytes = (uint8_t *)p;
         }
         HIP_TRY(c, launch_dictionary_gather(c->stream, (const int64_t *)d_dict_off,
-                                            (const uint8_t *)d_dict_bytes, dict_total,
+                                            (const uint8_t *)d_dict_bytes, dict_size, dict_total,
                                             (const int64_t *)d_idx, num_values, d_offsets, d_bytes));
     }
     mark(c, 3);

@@ -214,7 +214,7 @@ hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets
                                      uint64_t dict_total, const int64_t *indices, uint64_t n,
                                      uint64_t *lengths_out, uint32_t *error_flag);
 hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
-                                    const uint8_t *dict_bytes, uint64_t dict_total,
+                                    const uint8_t *dict_bytes, uint64_t dict_size, uint64_t dict_total,
                                     const int64_t *indices, uint64_t n, const int64_t *offsets_out,
                                     uint8_t *bytes_out);
 

@@ -5,6 +5,8 @@
 // consecutive slices of the DATA stream, i.e. value i starts at the exclusive prefix sum of the
 // lengths; tests/it/deserialize.rs:106-140 builds one String per value and validates UTF-8.  Here
 // the column is produced as offsets[n + 1] plus the contiguous bytes.
+#include <algorithm>
+
 #include "orcd_internal.h"
 
 namespace orcd {
@@ -387,23 +389,11 @@ __global__ __launch_bounds__(256) void dictionary_lengths_kernel(
     lengths_out[i] = l;
 }
 
-// One lane per value copies the entry's bytes: single bytes up to the first 4-byte boundary of
-// the destination, then whole dwords -- each put together from the two aligned source dwords it
-// straddles -- then the last bytes.  (A byte-sized access costs the memory pipeline as much per
-// lane as a dword-sized one; neighbouring lanes write neighbouring values, so the stores of a
-// wavefront fall into one stretch of the output.)
-__global__ __launch_bounds__(256) void dictionary_gather_kernel(
-    const int64_t *__restrict__ dict_offsets, const uint8_t *__restrict__ dict_bytes,
-    uint64_t dict_total, const int64_t *__restrict__ indices, uint64_t n,
-    const int64_t *__restrict__ offsets_out, uint8_t *__restrict__ bytes_out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t idx = (uint64_t)indices[i];
-    const uint64_t src0 = (uint64_t)dict_offsets[idx];
-    uint64_t len = (uint64_t)dict_offsets[idx + 1] - src0;
-    if (src0 > dict_total || len > dict_total - src0) return;  // checked before: never taken
-    const uint8_t *src = dict_bytes + src0;
-    uint8_t *dst = bytes_out + offsets_out[i];
+// len bytes from src to dst, both of any alignment: single bytes up to a 4-byte boundary of the
+// destination, then whole dwords -- each put together from the two aligned source dwords it
+// straddles -- then the last bytes.  No source dword past `last_word` (the aligned dword that
+// holds the dictionary's last byte) is read.
+__device__ __forceinline__ void copy_value(uint8_t *dst, const uint8_t *src, uint64_t len, uintptr_t last_word) {
     while (len && ((uintptr_t)dst & 3)) {
         *dst++ = *src++;
         len--;
@@ -411,7 +401,6 @@ __global__ __launch_bounds__(256) void dictionary_gather_kernel(
     if (len >= 4) {
         const uint32_t sh = (uint32_t)((uintptr_t)src & 3);
         const uint32_t *sw = (const uint32_t *)(src - sh);
-        const uintptr_t last_word = ((uintptr_t)(dict_bytes + dict_total - 1)) & ~(uintptr_t)3;
         uint32_t lo = *sw;
         while (len >= 4) {
             sw++;
@@ -432,6 +421,89 @@ __global__ __launch_bounds__(256) void dictionary_gather_kernel(
     }
 }
 
+// A wavefront takes 64 consecutive values: their bytes form one stretch of the output.  Each lane
+// copies its value out of the dictionary into an LDS image of that stretch (laid out at the
+// stretch's own 16-byte phase), and the wavefront then writes the image with 16-byte stores, 1 KiB
+// per instruction; the first and last 16 bytes, which neighbouring wavefronts share, go byte by
+// byte.  A stretch longer than the image is copied value by value straight to the output.
+// LDS_DICT: the dictionary itself (32-bit offsets + bytes) is small enough to live in LDS; every
+// workgroup copies it there once and then takes chunks of values in turn, so that the per-value
+// reads -- two offsets and a few dwords at a random place -- never leave the compute unit.
+constexpr uint32_t DG_IMAGE = 4096;        // bytes of output 64 values may hold to take the LDS way
+constexpr uint32_t DG_DICT_LDS = 48 << 10;  // dictionary offsets + bytes that may live in LDS
+
+template <bool LDS_DICT>
+__global__ __launch_bounds__(256) void dictionary_gather_kernel(
+    const int64_t *__restrict__ dict_offsets, const uint8_t *__restrict__ dict_bytes,
+    uint64_t dict_total, uint64_t dict_size, const int64_t *__restrict__ indices, uint64_t n,
+    const int64_t *__restrict__ offsets_out, uint8_t *__restrict__ bytes_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t image_all[4][DG_IMAGE + 32];
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
+    uint32_t *l_off = (uint32_t *)dyn;                                  // [dict_size + 1]
+    uint8_t *l_bytes = dyn + (((size_t)dict_size + 1) * 4 + 15) / 16 * 16;  // dictionary bytes at their own 4-byte phase
+    const uint32_t phase = (uint32_t)((uintptr_t)dict_bytes & 3);
+    if (LDS_DICT) {
+        for (uint64_t k = threadIdx.x; k <= dict_size; k += blockDim.x) l_off[k] = (uint32_t)dict_offsets[k];
+        const uint32_t *src = (const uint32_t *)(dict_bytes - phase);  // aligned dwords that each hold a dictionary byte
+        const uint64_t n_words = (dict_total + phase + 3) / 4;
+        for (uint64_t k = threadIdx.x; k < n_words; k += blockDim.x) ((uint32_t *)l_bytes)[k] = src[k];
+        __syncthreads();
+    }
+    uint8_t *image = image_all[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63;
+    const uintptr_t last_word = LDS_DICT ? ~(uintptr_t)0  // (the LDS copy is padded: a dword past the end may be read)
+                                         : ((uintptr_t)(dict_bytes + dict_total - 1)) & ~(uintptr_t)3;
+    const uint64_t n_chunks = (n + 63) / 64;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks;
+         chunk += (uint64_t)gridDim.x * 4) {
+        const uint64_t i0 = chunk * 64;
+        const uint64_t i = i0 + lane;
+        const bool live = i < n;
+        const uint64_t i_end = i0 + 64 < n ? i0 + 64 : n;
+        uint64_t src0 = 0, len = 0, off = 0;
+        if (live) {
+            const uint64_t idx = (uint64_t)indices[i];
+            off = (uint64_t)offsets_out[i];
+            if (idx < dict_size) {  // checked before: always
+                if (LDS_DICT) {
+                    src0 = l_off[idx];
+                    len = (uint64_t)l_off[idx + 1] - src0;
+                } else {
+                    src0 = (uint64_t)dict_offsets[idx];
+                    len = (uint64_t)dict_offsets[idx + 1] - src0;
+                }
+            }
+            if (src0 > dict_total || len > dict_total - src0) len = 0;  // checked before: never taken
+        }
+        const uint8_t *src = LDS_DICT ? l_bytes + phase + src0 : dict_bytes + src0;
+        const uint64_t o0 = (uint64_t)offsets_out[i0], o1 = (uint64_t)offsets_out[i_end];  // wave-uniform
+        const uint64_t total = o1 - o0;
+        if (o1 < o0 || total > DG_IMAGE) {
+            if (len) copy_value(bytes_out + off, src, len, last_word);
+            continue;
+        }
+        uint8_t *stretch = bytes_out + o0;
+        const uint32_t lead = (uint32_t)((uintptr_t)stretch & 15);
+        if (len && off >= o0 && off - o0 + len <= total)
+            copy_value(image + lead + (uint32_t)(off - o0), src, len, last_word);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // 16-byte pieces of the image [lead, lead + total): piece c holds image bytes [16c, 16c + 16)
+        const uint32_t end = lead + (uint32_t)total;
+        uint8_t *aligned = stretch - lead;
+        for (uint32_t c = lane; c * 16 < end; c += 64) {
+            const uint32_t b0 = c * 16, b1 = b0 + 16;
+            if (b0 >= lead && b1 <= end) {
+                *(uint4 *)(aligned + b0) = *(const uint4 *)(image + b0);
+            } else {
+                for (uint32_t b = b0 < lead ? lead : b0; b < (b1 < end ? b1 : end); b++) aligned[b] = image[b];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the next chunk's image writes come after these reads
+    }
+}
+
 hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
                                      uint64_t dict_total, const int64_t *indices, uint64_t n,
                                      uint64_t *lengths_out, uint32_t *error_flag) {
@@ -442,12 +514,20 @@ hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets
 }
 
 hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
-                                    const uint8_t *dict_bytes, uint64_t dict_total,
+                                    const uint8_t *dict_bytes, uint64_t dict_size, uint64_t dict_total,
                                     const int64_t *indices, uint64_t n, const int64_t *offsets_out,
                                     uint8_t *bytes_out) {
     if (n == 0) return hipSuccess;
-    dictionary_gather_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(
-        dict_offsets, dict_bytes, dict_total, indices, n, offsets_out, bytes_out);
+    const uint64_t chunks = (n + 63) / 64;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((chunks + 3) / 4, 256 * 8);  // workgroups take chunks in turn
+    const uint64_t lds = ((dict_size + 1) * 4 + 15) / 16 * 16 + dict_total + 16;
+    if (lds <= DG_DICT_LDS && dict_total < 0xFFFFFFFFull) {
+        dictionary_gather_kernel<true><<<blocks, 256, (size_t)lds, st>>>(
+            dict_offsets, dict_bytes, dict_total, dict_size, indices, n, offsets_out, bytes_out);
+    } else {
+        dictionary_gather_kernel<false><<<blocks, 256, 0, st>>>(
+            dict_offsets, dict_bytes, dict_total, dict_size, indices, n, offsets_out, bytes_out);
+    }
     return hipGetLastError();
 }
 

@@ -429,6 +429,29 @@ def test_strings_random(gpu, oracle):
     assert rc == 0 and (o_gpu == o_ref).all() and b_gpu.tobytes() == b_ref.tobytes()
 
 
+@pytest.mark.parametrize("shape", ["small_dict", "large_dict", "long_values", "empty_values"])
+def test_dictionary_gather_shapes(gpu, oracle, shape):
+    """The gather's ways through: dictionary held in LDS or read from memory, 64 values whose
+    bytes fit the LDS image or not, empty entries, every alignment of the output stretch."""
+    rng = np.random.default_rng(["small_dict", "large_dict", "long_values", "empty_values"].index(shape) + 40)
+    if shape == "small_dict":
+        lens = rng.integers(1, 30, size=300)
+    elif shape == "large_dict":
+        lens = rng.integers(1, 40, size=6000)       # 120 KB of bytes: not in LDS
+    elif shape == "long_values":
+        lens = rng.integers(0, 400, size=50)         # 64 values often exceed the image
+    else:
+        lens = rng.integers(0, 3, size=200)          # many empty entries
+    doff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    dbytes = rng.integers(0, 256, size=int(doff[-1]), dtype=np.uint8).tobytes()
+    for n in (1, 63, 64, 65, 1000, 20_001):
+        idx = rng.integers(0, lens.size, size=n)
+        rc, o_ref, b_ref = oracle.string_dictionary(doff, dbytes, idx)
+        assert rc == 0
+        rc, o_gpu, b_gpu = gpu.string_dictionary(doff, dbytes, idx)
+        assert rc == 0 and (o_gpu == o_ref).all() and b_gpu.tobytes() == b_ref.tobytes(), n
+
+
 # ---- device pointers and larger sizes ----------------------------------------------------------
 
 def test_device_pointers_and_properties():
