@@ -1093,22 +1093,31 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
         ORCD_TRY(ensure(c, SLOT_OUT_A, (num_values + 1) * sizeof(int64_t), &p));
         d_offsets = (int64_t *)p;
     }
-    void *flag, *sums;
+    if (num_values == 0) {
+        HIP_TRY(c, hipMemsetAsync(d_offsets, 0, sizeof(int64_t), c->stream));
+        if (!out_dev) ORCD_TRY(copy_out(c, offsets_out, d_offsets, sizeof(int64_t)));
+        return ORCD_OK;
+    }
+    // bytes per chunk of 64 values, their prefix sums, then offsets and bytes in one pass
+    const uint64_t n_chunks = ((uint64_t)num_values + 63) / 64;
+    void *flag, *sums, *chunk_sums;
     ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
-    ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(num_values) * sizeof(uint64_t), &sums));
+    ORCD_TRY(ensure(c, SLOT_TMP, (n_chunks + 1) * sizeof(uint64_t), &chunk_sums));
+    ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(n_chunks) * sizeof(uint64_t), &sums));
     HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
-    HIP_TRY(c, launch_dictionary_lengths(c->stream, (const int64_t *)d_dict_off, dict_size, dict_total,
-                                         (const int64_t *)d_idx, num_values, (uint64_t *)d_offsets,
-                                         (uint32_t *)flag));
-    // every length is <= dict_total here, so bit 0 cannot be raised by the scan
-    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)d_offsets, num_values, (uint64_t *)sums,
-                                         dict_total, (uint32_t *)flag));
-    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, d_offsets + num_values, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, launch_dictionary_chunk_sums(c->stream, (const int64_t *)d_dict_off, dict_size, dict_total,
+                                            (const int64_t *)d_idx, num_values, (uint64_t *)chunk_sums,
+                                            (uint32_t *)flag));
+    // (a chunk holds at most 64 * dict_total bytes; the limit only has to stay below 2^52)
+    const uint64_t chunk_limit = std::min<uint64_t>((uint64_t)dict_total * 64, (1ull << 52) - 1);
+    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)chunk_sums, n_chunks, (uint64_t *)sums,
+                                         chunk_limit, (uint32_t *)flag));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, (uint64_t *)chunk_sums + n_chunks, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint32_t bad = *(uint32_t *)(c->h_scalars + 1);
     if (bad & 2u) return ORCD_INVALID_ARGUMENT;  // dict_offsets do not describe dict_bytes
-    if (bad) return ORCD_OUT_OF_SPEC;
+    if (bad & 1u) return dict_total >= (1ull << 46) ? ORCD_INVALID_ARGUMENT : ORCD_OUT_OF_SPEC;
     const uint64_t total = c->h_scalars[0];
     if (total == ~0ull) return ORCD_INVALID_ARGUMENT;  // the column would exceed 2^64 bytes
     uint8_t *d_bytes = bytes_out;
@@ -1119,10 +1128,10 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
             ORCD_TRY(ensure(c, SLOT_OUT_B, total, &p));
             d_bytes = (uint8_t *)p;
         }
-        HIP_TRY(c, launch_dictionary_gather(c->stream, (const int64_t *)d_dict_off,
-                                            (const uint8_t *)d_dict_bytes, dict_size, dict_total,
-                                            (const int64_t *)d_idx, num_values, d_offsets, d_bytes));
     }
+    HIP_TRY(c, launch_dictionary_gather(c->stream, (const int64_t *)d_dict_off, (const uint8_t *)d_dict_bytes,
+                                        dict_size, dict_total, (const int64_t *)d_idx, num_values,
+                                        (const uint64_t *)chunk_sums, d_offsets, d_bytes));
     mark(c, 3);
     if (!out_dev) {
         ORCD_TRY(result_to_host(c, offsets_out, d_offsets, (num_values + 1) * sizeof(int64_t)));

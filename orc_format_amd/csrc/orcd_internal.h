@@ -210,13 +210,17 @@ hipError_t launch_exclusive_scan_u64(hipStream_t st, uint64_t *data, uint64_t n,
 hipError_t launch_string_bytes(hipStream_t st, const uint8_t *src, uint8_t *dst,
                                const int64_t *offsets, uint64_t n, uint64_t total_bytes,
                                uint32_t *invalid_flag);
-hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
-                                     uint64_t dict_total, const int64_t *indices, uint64_t n,
-                                     uint64_t *lengths_out, uint32_t *error_flag);
+// Dictionary strings: bytes per chunk of 64 values (indices and dictionary offsets checked: bit 0
+// of *error_flag an index out of range, bit 1 offsets that do not describe the dictionary), and,
+// given the exclusive prefix sums of those (n_chunks + 1 entries, the last one the total), the
+// values' offsets (n + 1) and -- bytes_out not null -- their bytes.
+hipError_t launch_dictionary_chunk_sums(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
+                                        uint64_t dict_total, const int64_t *indices, uint64_t n,
+                                        uint64_t *chunk_sums, uint32_t *error_flag);
 hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
                                     const uint8_t *dict_bytes, uint64_t dict_size, uint64_t dict_total,
-                                    const int64_t *indices, uint64_t n, const int64_t *offsets_out,
-                                    uint8_t *bytes_out);
+                                    const int64_t *indices, uint64_t n, const uint64_t *chunk_prefix,
+                                    int64_t *offsets_out, uint8_t *bytes_out);
 
 // Null scatter: per-tile counts of valid rows, then (after an exclusive scan of the counts)
 // out[r] = dense[number of valid rows before r] for valid rows, zero for null rows -- or the same

@@ -371,22 +371,32 @@ hipError_t launch_string_bytes(hipStream_t st, const uint8_t *src, uint8_t *dst,
 // dictionary gather (tests/it/deserialize.rs:142-185)
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void dictionary_lengths_kernel(
+// chunk_sums[c] = bytes that values [64c, 64c + 64) hold together (saturating); the indices and
+// the dictionary offsets are checked on the way.  The lengths themselves are never stored: the
+// gather recomputes them and places every value by a wave scan on top of the scanned chunk sums.
+__global__ __launch_bounds__(256) void dictionary_chunk_sums_kernel(
     const int64_t *__restrict__ dict_offsets, uint64_t dict_size, uint64_t dict_total,
-    const int64_t *__restrict__ indices, uint64_t n, uint64_t *__restrict__ lengths_out,
+    const int64_t *__restrict__ indices, uint64_t n, uint64_t *__restrict__ chunk_sums,
     uint32_t *__restrict__ error_flag) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t idx = (uint64_t)indices[i];
+    const uint32_t lane = threadIdx.x & 63;
+    if ((i & ~(uint64_t)63) >= n) return;  // whole wavefront
     uint64_t l = 0;
-    if (idx >= dict_size) {
-        atomicOr(error_flag, 1u);  // deserialize.rs:162 -> OutOfSpec
-    } else {
-        const uint64_t b = (uint64_t)dict_offsets[idx], e = (uint64_t)dict_offsets[idx + 1];
-        if (e < b || e > dict_total) atomicOr(error_flag, 2u);  // not offsets of dict_bytes
-        else l = e - b;
+    if (i < n) {
+        const uint64_t idx = (uint64_t)indices[i];
+        if (idx >= dict_size) {
+            atomicOr(error_flag, 1u);  // deserialize.rs:162 -> OutOfSpec
+        } else {
+            const uint64_t b = (uint64_t)dict_offsets[idx], e = (uint64_t)dict_offsets[idx + 1];
+            if (e < b || e > dict_total) atomicOr(error_flag, 2u);  // not offsets of dict_bytes
+            else l = e - b;
+        }
     }
-    lengths_out[i] = l;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)l, d), hi = __shfl_xor((uint32_t)(l >> 32), d);
+        l = sat_add(l, ((uint64_t)hi << 32) | lo);
+    }
+    if (lane == 0) chunk_sums[i >> 6] = l;
 }
 
 // len bytes from src to dst, both of any alignment: single bytes up to a 4-byte boundary of the
@@ -436,7 +446,8 @@ template <bool LDS_DICT>
 __global__ __launch_bounds__(256) void dictionary_gather_kernel(
     const int64_t *__restrict__ dict_offsets, const uint8_t *__restrict__ dict_bytes,
     uint64_t dict_total, uint64_t dict_size, const int64_t *__restrict__ indices, uint64_t n,
-    const int64_t *__restrict__ offsets_out, uint8_t *__restrict__ bytes_out) {
+    const uint64_t *__restrict__ chunk_prefix, int64_t *__restrict__ offsets_out,
+    uint8_t *__restrict__ bytes_out) {
     __shared__ __attribute__((aligned(16))) uint8_t image_all[4][DG_IMAGE + 32];
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
     uint32_t *l_off = (uint32_t *)dyn;                                  // [dict_size + 1]
@@ -459,11 +470,9 @@ __global__ __launch_bounds__(256) void dictionary_gather_kernel(
         const uint64_t i0 = chunk * 64;
         const uint64_t i = i0 + lane;
         const bool live = i < n;
-        const uint64_t i_end = i0 + 64 < n ? i0 + 64 : n;
-        uint64_t src0 = 0, len = 0, off = 0;
+        uint64_t src0 = 0, len = 0;
         if (live) {
             const uint64_t idx = (uint64_t)indices[i];
-            off = (uint64_t)offsets_out[i];
             if (idx < dict_size) {  // checked before: always
                 if (LDS_DICT) {
                     src0 = l_off[idx];
@@ -476,7 +485,19 @@ __global__ __launch_bounds__(256) void dictionary_gather_kernel(
             if (src0 > dict_total || len > dict_total - src0) len = 0;  // checked before: never taken
         }
         const uint8_t *src = LDS_DICT ? l_bytes + phase + src0 : dict_bytes + src0;
-        const uint64_t o0 = (uint64_t)offsets_out[i0], o1 = (uint64_t)offsets_out[i_end];  // wave-uniform
+        // where the chunk's bytes start and end, and this value's place among them
+        const uint64_t o0 = chunk_prefix[chunk], o1 = chunk_prefix[chunk + 1];  // wave-uniform
+        uint64_t incl = len;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = __shfl_up((uint32_t)incl, d), hi = __shfl_up((uint32_t)(incl >> 32), d);
+            if (lane >= (uint32_t)d) incl += ((uint64_t)hi << 32) | lo;
+        }
+        const uint64_t off = o0 + incl - len;
+        if (live) {
+            offsets_out[i] = (int64_t)off;
+            if (i + 1 == n) offsets_out[n] = (int64_t)(off + len);
+        }
+        if (!bytes_out) continue;  // offsets only
         const uint64_t total = o1 - o0;
         if (o1 < o0 || total > DG_IMAGE) {
             if (len) copy_value(bytes_out + off, src, len, last_word);
@@ -504,29 +525,29 @@ __global__ __launch_bounds__(256) void dictionary_gather_kernel(
     }
 }
 
-hipError_t launch_dictionary_lengths(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
-                                     uint64_t dict_total, const int64_t *indices, uint64_t n,
-                                     uint64_t *lengths_out, uint32_t *error_flag) {
+hipError_t launch_dictionary_chunk_sums(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
+                                        uint64_t dict_total, const int64_t *indices, uint64_t n,
+                                        uint64_t *chunk_sums, uint32_t *error_flag) {
     if (n == 0) return hipSuccess;
-    dictionary_lengths_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(
-        dict_offsets, dict_size, dict_total, indices, n, lengths_out, error_flag);
+    dictionary_chunk_sums_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(
+        dict_offsets, dict_size, dict_total, indices, n, chunk_sums, error_flag);
     return hipGetLastError();
 }
 
 hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
                                     const uint8_t *dict_bytes, uint64_t dict_size, uint64_t dict_total,
-                                    const int64_t *indices, uint64_t n, const int64_t *offsets_out,
-                                    uint8_t *bytes_out) {
+                                    const int64_t *indices, uint64_t n, const uint64_t *chunk_prefix,
+                                    int64_t *offsets_out, uint8_t *bytes_out) {
     if (n == 0) return hipSuccess;
     const uint64_t chunks = (n + 63) / 64;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((chunks + 3) / 4, 256 * 8);  // workgroups take chunks in turn
     const uint64_t lds = ((dict_size + 1) * 4 + 15) / 16 * 16 + dict_total + 16;
     if (lds <= DG_DICT_LDS && dict_total < 0xFFFFFFFFull) {
         dictionary_gather_kernel<true><<<blocks, 256, (size_t)lds, st>>>(
-            dict_offsets, dict_bytes, dict_total, dict_size, indices, n, offsets_out, bytes_out);
+            dict_offsets, dict_bytes, dict_total, dict_size, indices, n, chunk_prefix, offsets_out, bytes_out);
     } else {
         dictionary_gather_kernel<false><<<blocks, 256, 0, st>>>(
-            dict_offsets, dict_bytes, dict_total, dict_size, indices, n, offsets_out, bytes_out);
+            dict_offsets, dict_bytes, dict_total, dict_size, indices, n, chunk_prefix, offsets_out, bytes_out);
     }
     return hipGetLastError();
 }
