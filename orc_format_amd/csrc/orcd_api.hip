@@ -1064,6 +1064,36 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
     return ORCD_OK;
 }
 
+// First phase of a dictionary decode, all on the device: the bytes every chunk of 64 values
+// holds, scanned.  *chunk_prefix (in a buffer of the context, valid until its next call) gets
+// n_chunks + 1 entries, the last one the total, which *total receives too.  num_values > 0.
+static int dictionary_sums(orcd_ctx *c, const int64_t *d_dict_off, size_t dict_size, size_t dict_total,
+                           const int64_t *d_idx, size_t num_values, const uint64_t **chunk_prefix,
+                           uint64_t *total) {
+    const uint64_t n_chunks = ((uint64_t)num_values + 63) / 64;
+    void *flag, *sums, *chunk_sums;
+    ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
+    ORCD_TRY(ensure(c, SLOT_TMP, (n_chunks + 1) * sizeof(uint64_t), &chunk_sums));
+    ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(n_chunks) * sizeof(uint64_t), &sums));
+    HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, launch_dictionary_chunk_sums(c->stream, d_dict_off, dict_size, dict_total, d_idx, num_values,
+                                            (uint64_t *)chunk_sums, (uint32_t *)flag));
+    // (a chunk holds at most 64 * dict_total bytes; the limit only has to stay below 2^52)
+    const uint64_t chunk_limit = std::min<uint64_t>((uint64_t)dict_total * 64, (1ull << 52) - 1);
+    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)chunk_sums, n_chunks, (uint64_t *)sums,
+                                         chunk_limit, (uint32_t *)flag));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, (uint64_t *)chunk_sums + n_chunks, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t bad = *(uint32_t *)(c->h_scalars + 1);
+    if (bad & 2u) return ORCD_INVALID_ARGUMENT;  // dict_offsets do not describe dict_bytes
+    if (bad & 1u) return dict_total >= (1ull << 46) ? ORCD_INVALID_ARGUMENT : ORCD_OUT_OF_SPEC;
+    *total = c->h_scalars[0];
+    if (*total == ~0ull) return ORCD_INVALID_ARGUMENT;  // the column would exceed 2^64 bytes
+    *chunk_prefix = (const uint64_t *)chunk_sums;
+    return ORCD_OK;
+}
+
 int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
                                   const uint8_t *dict_bytes, size_t dict_size,
                                   const int64_t *indices, size_t num_values, int64_t *offsets_out,
@@ -1098,28 +1128,10 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
         if (!out_dev) ORCD_TRY(copy_out(c, offsets_out, d_offsets, sizeof(int64_t)));
         return ORCD_OK;
     }
-    // bytes per chunk of 64 values, their prefix sums, then offsets and bytes in one pass
-    const uint64_t n_chunks = ((uint64_t)num_values + 63) / 64;
-    void *flag, *sums, *chunk_sums;
-    ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
-    ORCD_TRY(ensure(c, SLOT_TMP, (n_chunks + 1) * sizeof(uint64_t), &chunk_sums));
-    ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(n_chunks) * sizeof(uint64_t), &sums));
-    HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
-    HIP_TRY(c, launch_dictionary_chunk_sums(c->stream, (const int64_t *)d_dict_off, dict_size, dict_total,
-                                            (const int64_t *)d_idx, num_values, (uint64_t *)chunk_sums,
-                                            (uint32_t *)flag));
-    // (a chunk holds at most 64 * dict_total bytes; the limit only has to stay below 2^52)
-    const uint64_t chunk_limit = std::min<uint64_t>((uint64_t)dict_total * 64, (1ull << 52) - 1);
-    HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)chunk_sums, n_chunks, (uint64_t *)sums,
-                                         chunk_limit, (uint32_t *)flag));
-    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, (uint64_t *)chunk_sums + n_chunks, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const uint32_t bad = *(uint32_t *)(c->h_scalars + 1);
-    if (bad & 2u) return ORCD_INVALID_ARGUMENT;  // dict_offsets do not describe dict_bytes
-    if (bad & 1u) return dict_total >= (1ull << 46) ? ORCD_INVALID_ARGUMENT : ORCD_OUT_OF_SPEC;
-    const uint64_t total = c->h_scalars[0];
-    if (total == ~0ull) return ORCD_INVALID_ARGUMENT;  // the column would exceed 2^64 bytes
+    uint64_t total = 0;
+    const uint64_t *chunk_prefix = nullptr;
+    ORCD_TRY(dictionary_sums(c, (const int64_t *)d_dict_off, dict_size, dict_total, (const int64_t *)d_idx,
+                             num_values, &chunk_prefix, &total));
     uint8_t *d_bytes = bytes_out;
     if (bytes_out) {
         if (total > bytes_capacity) return ORCD_INVALID_ARGUMENT;
@@ -1131,7 +1143,7 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
     }
     HIP_TRY(c, launch_dictionary_gather(c->stream, (const int64_t *)d_dict_off, (const uint8_t *)d_dict_bytes,
                                         dict_size, dict_total, (const int64_t *)d_idx, num_values,
-                                        (const uint64_t *)chunk_sums, d_offsets, d_bytes));
+                                        chunk_prefix, d_offsets, d_bytes));
     mark(c, 3);
     if (!out_dev) {
         ORCD_TRY(result_to_host(c, offsets_out, d_offsets, (num_values + 1) * sizeof(int64_t)));
@@ -1411,12 +1423,6 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
             // (the LENGTH stream of a dictionary has no ROW_INDEX positions of its own)
             ORCD_TRY(orcd_string_direct_decode(c, lb, ll, nullptr, 0, sb, sl, dict_size, (int64_t *)p.tmp,
                                                (uint8_t *)p.tmp2, io | utf8));
-            // longest entry: bounds the bytes of the gathered column
-            std::vector<int64_t> h_off((size_t)dict_size + 1);
-            HIP_TRY(c, hipMemcpyAsync(h_off.data(), p.tmp, h_off.size() * 8, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            int64_t longest = 0;
-            for (size_t i = 0; i < dict_size; i++) longest = std::max(longest, h_off[i + 1] - h_off[i]);
             // the indices: one per non-null row
             void *d_idx;
             ORCD_TRY(ensure(c, SLOT_OUT_B, n_values * 8, &d_idx));
@@ -1424,11 +1430,24 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
             size_t il;
             ORCD_TRY(cs.get(ORCD_STREAM_DATA, &ib, &il, &ent, &n_ent, n_values != 0));
             ORCD_TRY(orcd_rlev2_decode(c, ib, il, n_values, ent, n_ent, (int64_t *)d_idx, io));
-            const size_t cap = (size_t)longest * n_values;
-            ORCD_TRY(dev_alloc(c, cap, &p.bytes));
-            ORCD_TRY(orcd_string_dictionary_decode(c, (const int64_t *)p.tmp, (const uint8_t *)p.tmp2, dict_size,
-                                                   (const int64_t *)d_idx, n_values, (int64_t *)p.offsets,
-                                                   (uint8_t *)p.bytes, cap, ORCD_IN_DEVICE | ORCD_OUT_DEVICE));
+            // how many bytes the column holds is known after the first phase: the bytes array is
+            // allocated at exactly that size (a bound from the longest entry could be absurd)
+            if (n_values == 0) {
+                HIP_TRY(c, hipMemsetAsync(p.offsets, 0, 8, c->stream));
+                ORCD_TRY(dev_alloc(c, 0, &p.bytes));
+            } else {
+                HIP_TRY(c, hipMemcpyAsync(c->h_scalars, (int64_t *)p.tmp + dict_size, 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                const uint64_t dict_total = c->h_scalars[0];
+                uint64_t total = 0;
+                const uint64_t *chunk_prefix = nullptr;
+                ORCD_TRY(dictionary_sums(c, (const int64_t *)p.tmp, dict_size, dict_total, (const int64_t *)d_idx,
+                                         n_values, &chunk_prefix, &total));
+                ORCD_TRY(dev_alloc(c, total, &p.bytes));
+                HIP_TRY(c, launch_dictionary_gather(c->stream, (const int64_t *)p.tmp, (const uint8_t *)p.tmp2,
+                                                    dict_size, dict_total, (const int64_t *)d_idx, n_values,
+                                                    chunk_prefix, (int64_t *)p.offsets, (uint8_t *)p.bytes));
+            }
         } else {
             return ORCD_UNSUPPORTED;  // RLE v1 encodings (README.md:23-25 of the crate: not implemented there either)
         }
