@@ -292,3 +292,35 @@ def test_file_sharded_over_ranks_equals_pyarrow(tmp_path):
     assert (a[a_valid] == np.array(want.column("a").drop_null().to_pylist())).all()
     assert (b == np.array(want.column("b").to_pylist())).all()
     assert s == want.column("s").to_pylist()
+
+
+def test_dictionary_column_of_a_written_file(tmp_path):
+    """A dictionary-encoded string column with nulls, many rows and one long entry, as the ORC C++
+    writer lays it out: dictionary + indices decoded and gathered on the device."""
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    from orc_format_amd import default_context, read
+    from orc_format_amd.proto import ColumnEncodingKind
+    rng = np.random.default_rng(9)
+    rows = 200_000
+    words = ["w%d" % k * (1 + k % 5) for k in range(300)] + ["x" * 5000, ""]
+    picks = rng.integers(0, len(words), size=rows)
+    col = pa.array([words[k] for k in picks], mask=rng.random(rows) < 0.15)
+    path = str(tmp_path / "dict.orc")
+    orc.write_table(pa.table({"s": col}), path, compression="uncompressed",
+                    dictionary_key_size_threshold=1.0)
+    md = read.read_metadata(path)
+    ctx = default_context()
+    want = orc.ORCFile(path).read().column("s").to_pylist()
+    got, first = [], 0
+    saw_dictionary = False
+    for stripe in range(len(md.stripes)):
+        footer = read.read_stripe_footer(md, stripe)
+        saw_dictionary |= read.read_stripe_column(md, stripe, footer, 1).encoding() == ColumnEncodingKind.DictionaryV2
+        for d in (ctx.decode_column(md, stripe, footer, 1, row_aligned=True),
+                  ctx.decode_stripe(md, stripe, footer, [1], row_aligned=True)[0]):
+            off, raw, valid = d["offsets"], d["bytes"].tobytes(), d["validity"]
+            vals = [raw[off[i]:off[i + 1]].decode() if valid[i] else None for i in range(valid.size)]
+            assert vals == want[first:first + valid.size], stripe
+        first += valid.size
+    assert first == rows and saw_dictionary
