@@ -50,7 +50,7 @@ def main():
     ctx = Context(0)
     lib = N.lib()
 
-    def gpu(per_stripe):
+    def gpu(per_stripe, out_flag=N.OUT_DEVICE):
         md = read.read_metadata(path)
         for stripe in range(len(md.stripes)):
             footer = read.read_stripe_footer(md, stripe)
@@ -59,7 +59,7 @@ def main():
                 arr = (C.c_uint32 * len(columns))(*columns)
                 cds = (N.ColumnData * len(columns))()
                 check(lib.orcd_decode_stripe(ctx.handle, md._h, stripe, footer._h, arr, len(columns),
-                                             N.OUT_DEVICE | N.CHECK_UTF8, cds), ctx.handle)
+                                             out_flag | N.CHECK_UTF8, cds), ctx.handle)
                 for cd in cds:
                     lib.orcd_column_data_free(C.byref(cd))
             else:
@@ -106,8 +106,9 @@ def main():
             c.synchronize()
 
     t_two = best_of(gpu_two)
+    t_host = best_of(lambda: gpu(True, 0))   # results copied back into malloc'd host arrays
     for name, t in (("pyarrow (host)", t_arrow), ("per column", t_col), ("per stripe", t_stripe),
-                    ("2 contexts", t_two)):
+                    ("2 contexts", t_two), ("stripe -> host", t_host)):
         print("%-15s %.1f ms  %.2f GB/s of file" % (name, t * 1e3, size / t / 1e9), flush=True)
 
 

@@ -300,11 +300,13 @@ int orcd_scatter_valid(orcd_ctx *ctx, const uint8_t *validity, size_t num_rows, 
 
 /* One column of one stripe, decoded: what the deserialize_* functions of the crate's harness return
  * (tests/it/deserialize.rs:13-222), for the column's ORC type.  Arrays are owned by the structure
- * (release with orcd_column_data_free) and live in host memory, or in device memory when the call
- * had ORCD_OUT_DEVICE.  Released device arrays go back to the context, which hands the memory to
- * its next calls without waiting for the device: work on other streams that still reads them must
- * be finished (or ordered before the context's stream) when they are released, and they are
- * released before the context is destroyed. */
+ * (release with orcd_column_data_free) and live in host memory -- pinned, so that the copy from
+ * the device runs at the speed of the link -- or in device memory when the call had
+ * ORCD_OUT_DEVICE.  Either way they come from a cache of the context: released arrays go back to
+ * it and serve its next calls (orcd_ctx_release_cached empties it).  A device array is handed on
+ * without waiting for the device: work on other streams that still reads it must be finished (or
+ * ordered before the context's stream) when it is released.  All arrays are released before the
+ * context is destroyed. */
 typedef struct {
     int type_kind;        /* proto Type.Kind of the column (src/proto.rs:181-203) */
     int on_device;        /* where the arrays below live */
@@ -318,7 +320,7 @@ typedef struct {
     int64_t *offsets;     /* STRING / VARCHAR / CHAR / BINARY: [num_slots + 1] offsets into `bytes` */
     uint8_t *bytes;       /* the values' bytes, concatenated */
     uint64_t num_bytes;
-    orcd_ctx *owner;      /* device arrays only: the context that keeps released blocks for its next calls */
+    orcd_ctx *owner;      /* the context whose cache the arrays came from and go back to */
 } orcd_column_data;
 
 /* Reads column `column` of stripe `stripe` (one seek, one read, as read_stripe_column), finds its

@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -49,6 +51,125 @@ constexpr int N_EVENTS = 5;  // start, after header count + scan, after emit, af
 
 }  // namespace
 
+// Blocks of device or pinned host memory that a context keeps when they are released and hands
+// out again (see dev_alloc).
+struct BlockCache {
+    const bool host;
+    std::mutex lock;
+    std::multimap<size_t, void *> free_blocks;     // capacity -> block
+    std::unordered_map<void *, size_t> live;       // block in use -> capacity
+    size_t held = 0;                               // bytes in free_blocks
+    explicit BlockCache(bool h) : host(h) {}
+    hipError_t raw_alloc(void **p, size_t n) const { return host ? hipHostMalloc(p, n, hipHostMallocDefault) : hipMalloc(p, n); }
+    void raw_free(void *p) const {
+        if (host) (void)hipHostFree(p);
+        else (void)hipFree(p);
+    }
+    hipError_t take(size_t bytes, void **p) {
+        *p = nullptr;
+        const size_t want = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+        std::lock_guard<std::mutex> g(lock);
+        auto it = free_blocks.lower_bound(want);
+        if (it != free_blocks.end() && it->first <= want + want / 2 + 4096) {  // a block that fits without much waste
+            *p = it->second;
+            held -= it->first;
+            live[*p] = it->first;
+            free_blocks.erase(it);
+            return hipSuccess;
+        }
+        const hipError_t e = raw_alloc(p, want);
+        if (e == hipSuccess) live[*p] = want;
+        return e;
+    }
+    // false: not a block of this cache
+    bool give_back(void *p, size_t max_held) {
+        std::lock_guard<std::mutex> g(lock);
+        auto it = live.find(p);
+        if (it == live.end()) return false;
+        const size_t cap = it->second;
+        live.erase(it);
+        if (held + cap > max_held) {
+            raw_free(p);
+        } else {
+            free_blocks.emplace(cap, p);
+            held += cap;
+        }
+        return true;
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> g(lock);
+        for (auto &kv : free_blocks) raw_free(kv.second);
+        free_blocks.clear();
+        held = 0;
+    }
+};
+
+// The host threads of a context that move large transfers (see run_chunked): started on first
+// use, parked between transfers, joined when the context is destroyed.
+struct CopyThreads {
+    std::vector<std::thread> threads;  // thread k serves as worker k + 1; the caller is worker 0
+    std::mutex m;
+    std::condition_variable wake, done;
+    std::function<void(int)> job;
+    uint64_t generation = 0;
+    int n_active = 0, pending = 0;
+    bool stop = false;
+
+    void serve(int t) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(int)> fn;
+            bool mine;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                wake.wait(lock, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+                mine = t < n_active;
+                fn = job;
+            }
+            if (!mine) continue;
+            fn(t);
+            std::lock_guard<std::mutex> lock(m);
+            if (--pending == 0) done.notify_one();
+        }
+    }
+    // as many threads as can be had, up to `want`; returns how many there are
+    int ensure(int want) {
+        while ((int)threads.size() < want) {
+            const int t = (int)threads.size() + 1;
+            try {
+                threads.emplace_back([this, t] { serve(t); });
+            } catch (...) {
+                break;
+            }
+        }
+        return (int)threads.size();
+    }
+    // fn(0) here and fn(1..n-1) on the threads; returns when all are done (n - 1 <= threads.size())
+    void run(int n, const std::function<void(int)> &fn) {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            job = fn;
+            n_active = n;
+            pending = n - 1;
+            generation++;
+        }
+        wake.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lock(m);
+        done.wait(lock, [&] { return pending == 0; });
+    }
+    ~CopyThreads() {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            stop = true;
+        }
+        wake.notify_all();
+        for (auto &th : threads) th.join();
+    }
+};
+
 struct orcd_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -62,12 +183,11 @@ struct orcd_ctx {
     uint8_t *h_stage[N_READERS] = {};  // pinned chunks for large host transfers, allocated on first use
     hipEvent_t ev_stage[N_READERS] = {};
     bool stage_busy[N_READERS] = {};   // a copy out of the chunk was queued and not yet waited for
+    CopyThreads *copy_threads = nullptr;
     // Result arrays and per-call temporaries of the column calls: released blocks are kept and
     // handed out again (see dev_alloc).
-    std::mutex cache_lock;
-    std::multimap<size_t, void *> cache_free;       // capacity -> block
-    std::unordered_map<void *, size_t> cache_live;  // block in use -> capacity
-    size_t cache_held = 0;                          // bytes in cache_free
+    BlockCache dev_cache{false};   // device memory
+    BlockCache host_cache{true};   // pinned host memory: host results of the column calls
     hipError_t last_hip = hipSuccess;
 };
 
@@ -122,15 +242,25 @@ struct HostSource {       // where the bytes of a transfer to the device come fr
     const uint8_t *mem;   // ... or host memory
 };
 
-// one chunk-sized step of thread t: returns an ORCD status, hip errors in *hip
+// one chunk-sized step of worker t: returns an ORCD status, hip errors in *hip.  Chunks are as
+// large as the pinned chunks for long transfers and down to CHUNK_MIN for short ones, so that a
+// transfer of a few megabytes still spreads over the workers.
+constexpr size_t CHUNK_MIN = 1u << 20;
+
 template <typename Step>
 int run_chunked(orcd_ctx *c, uint64_t len, Step step) {
     for (int i = 0; i < N_READERS; i++) {
         if (!c->h_stage[i]) HIP_TRY(c, hipHostMalloc((void **)&c->h_stage[i], STAGE_CHUNK, hipHostMallocDefault));
         if (!c->ev_stage[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
     }
-    const uint64_t n_chunks = (len + STAGE_CHUNK - 1) / STAGE_CHUNK;
-    const int n_threads = (int)std::min<uint64_t>(N_READERS, n_chunks);
+    uint64_t chunk = (len / N_READERS + CHUNK_MIN - 1) / CHUNK_MIN * CHUNK_MIN;
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, CHUNK_MIN), STAGE_CHUNK);
+    const uint64_t n_chunks = (len + chunk - 1) / chunk;
+    int n_threads = (int)std::min<uint64_t>(N_READERS, n_chunks);
+    if (n_threads > 1) {
+        if (!c->copy_threads) c->copy_threads = new (std::nothrow) CopyThreads();
+        n_threads = c->copy_threads ? std::min(n_threads, c->copy_threads->ensure(n_threads - 1) + 1) : 1;
+    }
     std::atomic<int> status{ORCD_OK};
     std::atomic<int> hip_status{(int)hipSuccess};
     auto worker = [&](int t) {
@@ -139,7 +269,7 @@ int run_chunked(orcd_ctx *c, uint64_t len, Step step) {
             return;
         }
         for (uint64_t k = (uint64_t)t; k < n_chunks && status == ORCD_OK; k += (uint64_t)n_threads) {
-            const uint64_t pos = k * STAGE_CHUNK, n = std::min<uint64_t>(STAGE_CHUNK, len - pos);
+            const uint64_t pos = k * chunk, n = std::min<uint64_t>(chunk, len - pos);
             hipError_t e = hipSuccess;
             const int rc = step(t, pos, n, &e);
             if (rc != ORCD_OK) {
@@ -150,21 +280,9 @@ int run_chunked(orcd_ctx *c, uint64_t len, Step step) {
         }
     };
     if (n_threads <= 1) {
-        if (n_threads == 1) worker(0);
+        if (n_chunks) worker(0);
     } else {
-        // (a thread that cannot be started leaves its chunks undone: they are done here afterwards)
-        std::vector<std::thread> pool;
-        std::vector<int> not_started;
-        for (int t = 1; t < n_threads; t++) {
-            try {
-                pool.emplace_back(worker, t);
-            } catch (...) {
-                not_started.push_back(t);
-            }
-        }
-        worker(0);
-        for (auto &th : pool) th.join();
-        for (int t : not_started) worker(t);
+        c->copy_threads->run(n_threads, worker);
     }
     if (status != ORCD_OK) {
         if (hip_status != (int)hipSuccess) c->last_hip = (hipError_t)hip_status.load();
@@ -543,7 +661,9 @@ int orcd_ctx_destroy(orcd_ctx *c) {
         if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
         if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
     }
-    for (auto &kv : c->cache_free) (void)hipFree(kv.second);
+    c->dev_cache.release_all();
+    c->host_cache.release_all();
+    delete c->copy_threads;
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return ORCD_OK;
@@ -561,10 +681,8 @@ int orcd_ctx_release_cached(orcd_ctx *c) {
     if (!c) return ORCD_INVALID_ARGUMENT;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // queued work may still use a released block
-    std::lock_guard<std::mutex> lock(c->cache_lock);
-    for (auto &kv : c->cache_free) (void)hipFree(kv.second);
-    c->cache_free.clear();
-    c->cache_held = 0;
+    c->dev_cache.release_all();
+    c->host_cache.release_all();
     return ORCD_OK;
 }
 
@@ -1257,60 +1375,42 @@ struct ColumnStreams {
 // too; the runtime's own memory pools give large blocks back just the same), and a column takes
 // a handful of each: released blocks are kept by the context and handed out again -- to work that
 // is queued on the context's stream after whatever used them before, so no wait is needed.
-constexpr size_t CACHE_MAX_HELD = 64ull << 30;  // beyond this, released blocks go back to the runtime
+constexpr size_t CACHE_MAX_HELD = 64ull << 30;       // beyond this, released blocks go back to the runtime
+constexpr size_t HOST_CACHE_MAX_HELD = 32ull << 30;
 
 int dev_alloc(orcd_ctx *c, size_t bytes, void **p) {
-    *p = nullptr;
-    const size_t want = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
-    std::lock_guard<std::mutex> g(c->cache_lock);
-    auto it = c->cache_free.lower_bound(want);
-    if (it != c->cache_free.end() && it->first <= want + want / 2 + 4096) {  // a block that fits without much waste
-        *p = it->second;
-        c->cache_held -= it->first;
-        c->cache_live[*p] = it->first;
-        c->cache_free.erase(it);
-        return ORCD_OK;
-    }
-    HIP_TRY(c, hipMalloc(p, want));
-    c->cache_live[*p] = want;
+    HIP_TRY(c, c->dev_cache.take(bytes, p));
     return ORCD_OK;
 }
 
 void dev_free(orcd_ctx *c, void *p) {
     if (!p) return;
-    std::lock_guard<std::mutex> g(c->cache_lock);
-    auto it = c->cache_live.find(p);
-    if (it == c->cache_live.end()) {  // not one of ours
-        (void)hipFree(p);
-        return;
-    }
-    const size_t cap = it->second;
-    c->cache_live.erase(it);
-    if (c->cache_held + cap > CACHE_MAX_HELD) {
-        (void)hipFree(p);
-        return;
-    }
-    c->cache_free.emplace(cap, p);
-    c->cache_held += cap;
+    if (!c->dev_cache.give_back(p, CACHE_MAX_HELD)) (void)hipFree(p);  // not one of ours
 }
 
-// Moves a device result array to where the caller wants it: stays (device) or a malloc'd copy.
+// Host results of the column calls live in pinned memory from a cache of the same kind: a copy
+// from the device into it runs at the speed of the link (into freshly malloc'd pageable memory it
+// ran at 6-14 GB/s, page faults and the runtime's staging included), and pinning is paid once.
+void host_free(orcd_ctx *c, void *p) {
+    if (!p) return;
+    if (!c->host_cache.give_back(p, HOST_CACHE_MAX_HELD)) (void)hipHostFree(p);
+}
+
+// Moves a device result array to where the caller wants it: stays (device) or a host copy.
 int deliver(orcd_ctx *c, void *d_ptr, size_t bytes, bool out_dev, void **result) {
     if (out_dev) {
         *result = d_ptr;
         return ORCD_OK;
     }
-    void *h = malloc(bytes ? bytes : 1);
-    if (!h) {
-        dev_free(c, d_ptr);
-        return ORCD_HIP_ERROR;
-    }
-    int rc = result_to_host(c, h, d_ptr, bytes);
-    if (rc == ORCD_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = ORCD_HIP_ERROR;
+    void *h = nullptr;
+    hipError_t e = c->host_cache.take(bytes, &h);
+    if (e == hipSuccess && bytes) e = hipMemcpyAsync(h, d_ptr, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     dev_free(c, d_ptr);
-    if (rc != ORCD_OK) {
-        free(h);
-        return rc;
+    if (e != hipSuccess) {
+        host_free(c, h);
+        c->last_hip = e;
+        return ORCD_HIP_ERROR;
     }
     *result = h;
     return ORCD_OK;
@@ -1491,7 +1591,7 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
     out->num_slots = slots;
     out->value_size = value_size;
     out->num_bytes = num_bytes;
-    out->owner = out_dev ? c : nullptr;
+    out->owner = c;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     void *r;
     int rc = deliver(c, p.validity, rows, out_dev, &r);
@@ -1735,9 +1835,9 @@ void orcd_column_data_free(orcd_column_data *d) {
     if (!d) return;
     for (void *p : {(void *)d->validity, d->values, (void *)d->offsets, (void *)d->bytes}) {
         if (!p) continue;
-        if (!d->on_device) free(p);
-        else if (d->owner) dev_free(d->owner, p);  // back to the context that made it
-        else (void)hipFree(p);
+        if (!d->owner) continue;  // (every array a column call returns has one)
+        if (d->on_device) dev_free(d->owner, p);  // back to the context that made it
+        else host_free(d->owner, p);
     }
     memset(d, 0, sizeof(*d));
 }
