@@ -41,7 +41,8 @@ enum {
     ORCD_INVALID_PROTO = 7,
     ORCD_UNSUPPORTED = 100, /* the crate panics with todo!() here (e.g. compressed files) */
     ORCD_HIP_ERROR = 101,
-    ORCD_INVALID_ARGUMENT = 102
+    ORCD_INVALID_ARGUMENT = 102,
+    ORCD_NO_MEMORY = 103 /* host memory ran out inside the library */
 };
 
 /* ---- flags ---------------------------------------------------------------------------------- */

@@ -20,6 +20,13 @@
 
 using namespace orcd;
 
+// No exception leaves the C ABI: host allocations (std::vector, new) and thread or lock creation
+// are the only things here that throw.
+#define ORCD_CATCH                                     \
+    catch (...) {                                      \
+        return ORCD_NO_MEMORY;                         \
+    }
+
 namespace {
 
 enum Slot {
@@ -622,11 +629,12 @@ const char *orcd_strerror(int status) {
     case ORCD_UNSUPPORTED: return "unsupported feature";
     case ORCD_HIP_ERROR: return "HIP runtime error";
     case ORCD_INVALID_ARGUMENT: return "invalid argument";
+    case ORCD_NO_MEMORY: return "out of host memory";
     default: return "unknown status";
     }
 }
 
-int orcd_ctx_create(int device_id, orcd_ctx **out) {
+int orcd_ctx_create(int device_id, orcd_ctx **out) try {
     if (!out) return ORCD_INVALID_ARGUMENT;
     *out = nullptr;
     int n = 0;
@@ -645,9 +653,9 @@ int orcd_ctx_create(int device_id, orcd_ctx **out) {
     c->stream = c->own_stream;
     *out = c;
     return ORCD_OK;
-}
+} ORCD_CATCH
 
-int orcd_ctx_destroy(orcd_ctx *c) {
+int orcd_ctx_destroy(orcd_ctx *c) try {
     if (!c) return ORCD_OK;
     DeviceGuard g(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -667,31 +675,31 @@ int orcd_ctx_destroy(orcd_ctx *c) {
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return ORCD_OK;
-}
+} ORCD_CATCH
 
-int orcd_ctx_set_stream(orcd_ctx *c, void *hip_stream) {
+int orcd_ctx_set_stream(orcd_ctx *c, void *hip_stream) try {
     if (!c) return ORCD_INVALID_ARGUMENT;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return ORCD_OK;
-}
+} ORCD_CATCH
 
-int orcd_ctx_release_cached(orcd_ctx *c) {
+int orcd_ctx_release_cached(orcd_ctx *c) try {
     if (!c) return ORCD_INVALID_ARGUMENT;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // queued work may still use a released block
     c->dev_cache.release_all();
     c->host_cache.release_all();
     return ORCD_OK;
-}
+} ORCD_CATCH
 
-int orcd_ctx_synchronize(orcd_ctx *c) {
+int orcd_ctx_synchronize(orcd_ctx *c) try {
     if (!c) return ORCD_INVALID_ARGUMENT;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 float orcd_ctx_phase_ms(orcd_ctx *c, int phase) {
     if (!c || phase < 0 || phase >= N_EVENTS) return -1.0f;
@@ -721,7 +729,7 @@ const char *orcd_ctx_last_hip_error(orcd_ctx *c) {
 
 int orcd_rlev2_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_values,
                       const uint64_t *entry_points, size_t n_entries, int64_t *out,
-                      unsigned flags) {
+                      unsigned flags) try {
     if (!c || (len && !stream) || (num_values && !out) || (n_entries && !entry_points))
         return ORCD_INVALID_ARGUMENT;
     if (num_values == 0) return ORCD_OK;
@@ -743,7 +751,7 @@ int orcd_rlev2_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num
                           n_entries, (flags & ORCD_SIGNED) ? 1 : 0, d_out));
     if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, num_values * sizeof(int64_t)));
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 }  // extern "C"
 
@@ -820,7 +828,7 @@ extern "C" {
 
 int orcd_rlev2_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_len,
                             const orcd_rlev2_slice *slices, size_t n_slices, int64_t *out,
-                            size_t *bad_slice, unsigned flags) {
+                            size_t *bad_slice, unsigned flags) try {
     if (bad_slice) *bad_slice = (size_t)-1;
     if (!c || (buffer_len && !buffer) || (n_slices && !slices)) return ORCD_INVALID_ARGUMENT;
     SegmentPlan plan;
@@ -858,11 +866,11 @@ int orcd_rlev2_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_le
     mark(c, 3);
     if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, total_values * sizeof(int64_t)));
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 int orcd_boolean_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_len,
                               const orcd_rlev2_slice *slices, size_t n_slices, uint8_t *out_bytes,
-                              uint64_t *set_bits, size_t *bad_slice, unsigned flags) {
+                              uint64_t *set_bits, size_t *bad_slice, unsigned flags) try {
     if (bad_slice) *bad_slice = (size_t)-1;
     if (!c || (buffer_len && !buffer) || (n_slices && !slices)) return ORCD_INVALID_ARGUMENT;
     if (set_bits)
@@ -924,11 +932,11 @@ int orcd_boolean_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_
     }
     if (!out_dev) ORCD_TRY(copy_out(c, out_bytes, d_out, total_bytes * 8));
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 int orcd_rlev2_runs(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_values,
                     const uint64_t *entry_points, size_t n_entries, orcd_run *runs,
-                    size_t max_runs, size_t *n_runs, unsigned flags) {
+                    size_t max_runs, size_t *n_runs, unsigned flags) try {
     if (!c || (len && !stream) || !n_runs || (max_runs && !runs) || (n_entries && !entry_points))
         return ORCD_INVALID_ARGUMENT;
     *n_runs = 0;
@@ -967,13 +975,13 @@ int orcd_rlev2_runs(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_v
     }
     *n_runs = count;
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 // ---- byte-RLE and booleans ------------------------------------------------------------------
 
 int orcd_byte_rle_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_bytes,
                          const uint64_t *entry_points, size_t n_entries, uint8_t *out,
-                         unsigned flags) {
+                         unsigned flags) try {
     if (!c || (len && !stream) || (num_bytes && !out) || (n_entries && !entry_points))
         return ORCD_INVALID_ARGUMENT;
     if (num_bytes == 0) return ORCD_OK;
@@ -995,11 +1003,11 @@ int orcd_byte_rle_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t 
                              n_entries, d_out));
     if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, num_bytes));
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 int orcd_boolean_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_bits,
                         const uint64_t *entry_points, size_t n_entries, uint8_t *out_bytes,
-                        uint8_t *out_bitmap, uint64_t *set_bits, unsigned flags) {
+                        uint8_t *out_bitmap, uint64_t *set_bits, unsigned flags) try {
     if (!c || (len && !stream) || (n_entries && !entry_points)) return ORCD_INVALID_ARGUMENT;
     if (set_bits) *set_bits = 0;
     if (num_bits == 0) return ORCD_OK;
@@ -1045,12 +1053,12 @@ int orcd_boolean_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t n
     if (d_count || !out_dev) HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (set_bits) *set_bits = c->h_scalars[0];
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 // ---- floats ---------------------------------------------------------------------------------
 
 int orcd_float_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t elem_size,
-                      size_t num_values, void *out, unsigned flags) {
+                      size_t num_values, void *out, unsigned flags) try {
     if (!c || (len && !stream) || (num_values && !out)) return ORCD_INVALID_ARGUMENT;
     if (elem_size != 4 && elem_size != 8) return ORCD_INVALID_ARGUMENT;
     if (num_values > len / elem_size) return ORCD_DECODE_FLOAT;  // float.rs:78-81
@@ -1067,14 +1075,14 @@ int orcd_float_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t ele
     mark(c, 3);
     if (!out_dev) HIP_TRY(c, hipStreamSynchronize(c->stream));
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 // ---- strings --------------------------------------------------------------------------------
 
 int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t length_len,
                               const uint64_t *length_entry_points, size_t n_length_entries,
                               const uint8_t *data, size_t data_len, size_t num_values,
-                              int64_t *offsets, uint8_t *bytes_out, unsigned flags) {
+                              int64_t *offsets, uint8_t *bytes_out, unsigned flags) try {
     if (!c || !offsets || (length_len && !length_stream) || (data_len && !data) ||
         (n_length_entries && !length_entry_points))
         return ORCD_INVALID_ARGUMENT;
@@ -1180,7 +1188,7 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 // First phase of a dictionary decode, all on the device: the bytes every chunk of 64 values
 // holds, scanned.  *chunk_prefix (in a buffer of the context, valid until its next call) gets
@@ -1215,7 +1223,7 @@ static int dictionary_sums(orcd_ctx *c, const int64_t *d_dict_off, size_t dict_s
 int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
                                   const uint8_t *dict_bytes, size_t dict_size,
                                   const int64_t *indices, size_t num_values, int64_t *offsets_out,
-                                  uint8_t *bytes_out, size_t bytes_capacity, unsigned flags) {
+                                  uint8_t *bytes_out, size_t bytes_capacity, unsigned flags) try {
     if (!c || !offsets_out || !dict_offsets || (num_values && !indices)) return ORCD_INVALID_ARGUMENT;
     DeviceGuard g(c->device);
     reset_events(c);
@@ -1270,7 +1278,7 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 // ---- null scatter ---------------------------------------------------------------------------
 
@@ -1301,7 +1309,7 @@ int scatter_device(orcd_ctx *c, const uint8_t *d_validity, size_t num_rows, cons
 }  // namespace
 
 int orcd_scatter_valid(orcd_ctx *c, const uint8_t *validity, size_t num_rows, const void *dense,
-                       size_t num_values, size_t elem_size, void *out, unsigned flags) {
+                       size_t num_values, size_t elem_size, void *out, unsigned flags) try {
     if (!c || (num_rows && (!validity || !out)) || (num_values && !dense)) return ORCD_INVALID_ARGUMENT;
     if (elem_size != 1 && elem_size != 4 && elem_size != 8) return ORCD_INVALID_ARGUMENT;
     const bool carry = flags & ORCD_SCATTER_CARRY;
@@ -1321,7 +1329,7 @@ int orcd_scatter_valid(orcd_ctx *c, const uint8_t *validity, size_t num_rows, co
     mark(c, 3);
     if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, num_rows * elem_size));
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 // ---- whole columns --------------------------------------------------------------------------
 
@@ -1797,7 +1805,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
 }  // namespace
 
 int orcd_decode_stripe(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
-                       const uint32_t *columns, size_t n_columns, unsigned flags, orcd_column_data *out) {
+                       const uint32_t *columns, size_t n_columns, unsigned flags, orcd_column_data *out) try {
     if (!c || !file || !footer || (n_columns && (!columns || !out))) return ORCD_INVALID_ARGUMENT;
     for (size_t i = 0; i < n_columns; i++) memset(&out[i], 0, sizeof(out[i]));
     if (orcd_file_compression(file) != 0) return ORCD_UNSUPPORTED;  // chunk framing is not decoded here
@@ -1812,10 +1820,10 @@ int orcd_decode_stripe(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     if (rc != ORCD_OK)
         for (size_t i = 0; i < n_columns; i++) orcd_column_data_free(&out[i]);
     return rc;
-}
+} ORCD_CATCH
 
 int orcd_decode_column(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
-                       uint32_t column, unsigned flags, orcd_column_data *out) {
+                       uint32_t column, unsigned flags, orcd_column_data *out) try {
     if (!c || !file || !footer || !out) return ORCD_INVALID_ARGUMENT;
     memset(out, 0, sizeof(*out));
     if (orcd_file_compression(file) != 0) return ORCD_UNSUPPORTED;  // chunk framing is not decoded here
@@ -1829,7 +1837,7 @@ int orcd_decode_column(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     orcd_column_free(col);
     if (rc != ORCD_OK) memset(out, 0, sizeof(*out));
     return rc;
-}
+} ORCD_CATCH
 
 void orcd_column_data_free(orcd_column_data *d) {
     if (!d) return;

@@ -13,6 +13,12 @@
 
 #include "../../include/orcd.h"
 
+// No exception leaves the C ABI: host allocations (std::vector, new) are what throws here.
+#define ORCD_CATCH                                     \
+    catch (...) {                                      \
+        return ORCD_NO_MEMORY;                         \
+    }
+
 namespace {
 
 constexpr uint64_t DEFAULT_FOOTER_SIZE = 16 * 1024;  // src/read/mod.rs:22
@@ -362,7 +368,7 @@ static int open_common(orcd_file *f, orcd_file **out) {
     return ORCD_OK;
 }
 
-int orcd_file_open(const char *path, orcd_file **out) {
+int orcd_file_open(const char *path, orcd_file **out) try {
     if (!path || !out) return ORCD_INVALID_ARGUMENT;
     *out = nullptr;
     FILE *fp = fopen(path, "rb");
@@ -375,16 +381,16 @@ int orcd_file_open(const char *path, orcd_file **out) {
     }
     f->src.len = (uint64_t)ftello(fp);
     return open_common(f, out);
-}
+} ORCD_CATCH
 
-int orcd_file_open_memory(const uint8_t *bytes, size_t len, orcd_file **out) {
+int orcd_file_open_memory(const uint8_t *bytes, size_t len, orcd_file **out) try {
     if (!bytes || !out) return ORCD_INVALID_ARGUMENT;
     *out = nullptr;
     orcd_file *f = new orcd_file();
     f->src.mem = bytes;
     f->src.len = len;
     return open_common(f, out);
-}
+} ORCD_CATCH
 
 void orcd_file_close(orcd_file *f) {
     if (!f) return;
@@ -394,23 +400,23 @@ void orcd_file_close(orcd_file *f) {
 
 size_t orcd_file_num_stripes(const orcd_file *f) { return f ? f->stripes.size() : 0; }
 
-int orcd_file_stripe(const orcd_file *f, size_t stripe, orcd_stripe_info *info) {
+int orcd_file_stripe(const orcd_file *f, size_t stripe, orcd_stripe_info *info) try {
     if (!f || !info || stripe >= f->stripes.size()) return ORCD_INVALID_ARGUMENT;
     *info = f->stripes[stripe];
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 int orcd_file_compression(const orcd_file *f) { return f ? f->compression : -1; }
 uint64_t orcd_file_number_of_rows(const orcd_file *f) { return f ? f->number_of_rows : 0; }
 uint32_t orcd_file_row_index_stride(const orcd_file *f) { return f ? f->row_index_stride : 0; }
 size_t orcd_file_num_types(const orcd_file *f) { return f ? f->types.size() : 0; }
 
-int orcd_file_type_kind(const orcd_file *f, size_t type_id) {
+int orcd_file_type_kind(const orcd_file *f, size_t type_id) try {
     if (!f || type_id >= f->types.size()) return -1;
     return f->types[type_id].kind;
-}
+} ORCD_CATCH
 
-int orcd_read_stripe_footer(orcd_file *f, size_t stripe, orcd_stripe_footer **out) {
+int orcd_read_stripe_footer(orcd_file *f, size_t stripe, orcd_stripe_footer **out) try {
     if (!f || !out) return ORCD_INVALID_ARGUMENT;
     *out = nullptr;
     if (stripe >= f->stripes.size()) return ORCD_INVALID_ARGUMENT;
@@ -427,20 +433,20 @@ int orcd_read_stripe_footer(orcd_file *f, size_t stripe, orcd_stripe_footer **ou
     }
     *out = ft;
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 void orcd_stripe_footer_free(orcd_stripe_footer *ft) { delete ft; }
 
 size_t orcd_stripe_footer_num_streams(const orcd_stripe_footer *ft) { return ft ? ft->streams.size() : 0; }
 
-int orcd_stripe_footer_stream(const orcd_stripe_footer *ft, size_t i, orcd_stream_info *info) {
+int orcd_stripe_footer_stream(const orcd_stripe_footer *ft, size_t i, orcd_stream_info *info) try {
     if (!ft || !info || i >= ft->streams.size()) return ORCD_INVALID_ARGUMENT;
     *info = ft->streams[i];
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 int orcd_read_stripe_column(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft,
-                            uint32_t column, orcd_column **out) {
+                            uint32_t column, orcd_column **out) try {
     if (!f || !ft || !out) return ORCD_INVALID_ARGUMENT;
     *out = nullptr;
     if (stripe >= f->stripes.size()) return ORCD_INVALID_ARGUMENT;
@@ -468,12 +474,12 @@ int orcd_read_stripe_column(orcd_file *f, size_t stripe, const orcd_stripe_foote
     col->footer = ft;
     *out = col;
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 void orcd_column_free(orcd_column *col) { delete col; }
 
 int orcd_stripe_column_open(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft, uint32_t column,
-                            orcd_column **out) {
+                            orcd_column **out) try {
     if (!f || !ft || !out) return ORCD_INVALID_ARGUMENT;
     *out = nullptr;
     if (stripe >= f->stripes.size()) return ORCD_INVALID_ARGUMENT;
@@ -488,9 +494,9 @@ int orcd_stripe_column_open(orcd_file *f, size_t stripe, const orcd_stripe_foote
     col->footer = ft;
     *out = col;
     return ORCD_OK;
-}
+} ORCD_CATCH
 
-int orcd_column_region(const orcd_column *col, uint64_t *offset, uint64_t *len) {
+int orcd_column_region(const orcd_column *col, uint64_t *offset, uint64_t *len) try {
     if (!col || !offset || !len) return ORCD_INVALID_ARGUMENT;
     // what read_stripe_column reads: from the column's first non-ROW_INDEX stream, as many bytes
     // as its streams hold together (src/read/mod.rs:129-144)
@@ -508,9 +514,9 @@ int orcd_column_region(const orcd_column *col, uint64_t *offset, uint64_t *len) 
     *offset = start;
     *len = length;
     return ORCD_OK;
-}
+} ORCD_CATCH
 
-int orcd_column_stream_range(const orcd_column *col, int kind, uint64_t *offset, uint64_t *len) {
+int orcd_column_stream_range(const orcd_column *col, int kind, uint64_t *offset, uint64_t *len) try {
     if (!col || !offset || !len) return ORCD_INVALID_ARGUMENT;
     uint64_t region = 0, region_len = 0;
     const int rc = orcd_column_region(col, &region, &region_len);
@@ -528,14 +534,14 @@ int orcd_column_stream_range(const orcd_column *col, int kind, uint64_t *offset,
         start += s.length;
     }
     return ORCD_INVALID_KIND;
-}
+} ORCD_CATCH
 
-int orcd_file_read_at(orcd_file *f, uint64_t offset, uint64_t len, uint8_t *dst) {
+int orcd_file_read_at(orcd_file *f, uint64_t offset, uint64_t len, uint8_t *dst) try {
     if (!f || (len && !dst)) return ORCD_INVALID_ARGUMENT;
     return f->src.read_into(offset, len, dst) ? ORCD_OK : ORCD_OUT_OF_SPEC;
-}
+} ORCD_CATCH
 
-int orcd_column_get_stream(const orcd_column *col, int kind, const uint8_t **bytes, size_t *len) {
+int orcd_column_get_stream(const orcd_column *col, int kind, const uint8_t **bytes, size_t *len) try {
     if (!col || !bytes || !len || !col->has_data) return ORCD_INVALID_ARGUMENT;
     // running offset over the column's non-ROW_INDEX streams (src/read/column.rs:38-55)
     uint64_t start = 0;
@@ -550,20 +556,20 @@ int orcd_column_get_stream(const orcd_column *col, int kind, const uint8_t **byt
         start += s.length;
     }
     return ORCD_INVALID_KIND;
-}
+} ORCD_CATCH
 
-int orcd_column_encoding(const orcd_column *col, int *kind, uint32_t *dictionary_size) {
+int orcd_column_encoding(const orcd_column *col, int *kind, uint32_t *dictionary_size) try {
     if (!col || col->column >= col->footer->columns.size()) return ORCD_INVALID_COLUMN;
     const Encoding &e = col->footer->columns[col->column];
     if (kind) *kind = e.kind;
     if (dictionary_size) *dictionary_size = e.has_dict ? e.dictionary_size : 0;
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 uint64_t orcd_column_number_of_rows(const orcd_column *col) { return col ? col->number_of_rows : 0; }
 
 int orcd_column_entry_points(orcd_file *f, orcd_column *col, int kind, const uint64_t **entries,
-                             size_t *n_entries) {
+                             size_t *n_entries) try {
     if (!f || !col || !entries || !n_entries || kind < 0 || kind >= 8) return ORCD_INVALID_ARGUMENT;
     if (!col->index_loaded) {
         col->index_status = load_entry_points(f, col);
@@ -574,6 +580,6 @@ int orcd_column_entry_points(orcd_file *f, orcd_column *col, int kind, const uin
     *entries = col->entries[kind].data();
     *n_entries = col->entries[kind].size();
     return ORCD_OK;
-}
+} ORCD_CATCH
 
 }  // extern "C"

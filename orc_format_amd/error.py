@@ -12,6 +12,7 @@ class OrcError(Exception):
         N.DECODE_FLOAT: "DecodeFloat", N.DECOMPRESSION: "Decompression",
         N.INVALID_PROTO: "InvalidProto", N.UNSUPPORTED: "Unsupported", N.HIP_ERROR: "HipError",
         N.INVALID_ARGUMENT: "InvalidArgument",
+        N.NO_MEMORY: "NoMemory",
     }
 
     def __init__(self, code, detail=""):

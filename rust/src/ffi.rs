@@ -18,6 +18,8 @@ pub const ORCD_DECOMPRESSION: c_int = 6;
 pub const ORCD_INVALID_PROTO: c_int = 7;
 pub const ORCD_UNSUPPORTED: c_int = 100;
 pub const ORCD_HIP_ERROR: c_int = 101;
+pub const ORCD_INVALID_ARGUMENT: c_int = 102;
+pub const ORCD_NO_MEMORY: c_int = 103;
 
 pub const ORCD_SIGNED: c_uint = 1;
 pub const ORCD_IN_DEVICE: c_uint = 2;
