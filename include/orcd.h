@@ -324,7 +324,7 @@ typedef struct {
     orcd_ctx *owner;      /* the context whose cache the arrays came from and go back to */
 } orcd_column_data;
 
-/* Reads column `column` of stripe `stripe` (one seek, one read, as read_stripe_column), finds its
+/* Reads column `column` of stripe `stripe` (the region read_stripe_column reads), finds its
  * streams and ROW_INDEX entry points and runs the decoders above.  Flags: ORCD_OUT_DEVICE,
  * ORCD_CHECK_UTF8 (STRING / VARCHAR / CHAR), ORCD_ROW_ALIGNED.  Departures from the harness, both
  * where the harness departs from the format: a column without PRESENT stream is all valid

@@ -1350,9 +1350,10 @@ struct StripeBytes {
 struct ColumnStreams {
     orcd_file *file;
     orcd_column *col;
-    const StripeBytes *dev;  // null: streams are host memory owned by `col`
-    // flags for the stream decoders: where the stream lies; results stay on the device
-    unsigned io() const { return ORCD_OUT_DEVICE | (dev ? (ORCD_IN_DEVICE | ORCD_ENTRIES_HOST) : 0u); }
+    const StripeBytes *dev;  // the device copy the column's streams lie in
+    // flags for the stream decoders: streams on the device, ROW_INDEX positions on the host,
+    // results stay on the device
+    unsigned io() const { return ORCD_OUT_DEVICE | ORCD_IN_DEVICE | ORCD_ENTRIES_HOST; }
     // a stream's bytes (empty when absent) and its ROW_INDEX entry points
     int get(int kind, const uint8_t **bytes, size_t *len, const uint64_t **entries, size_t *n_entries,
             bool required) const {
@@ -1360,20 +1361,13 @@ struct ColumnStreams {
         *len = 0;
         *entries = nullptr;
         *n_entries = 0;
-        int rc;
-        if (dev) {
-            uint64_t off = 0, n = 0;
-            rc = orcd_column_stream_range(col, kind, &off, &n);
-            if (rc == ORCD_OK) {
-                if (off < dev->lo || off > dev->hi || n > dev->hi - off) return ORCD_OUT_OF_SPEC;
-                *bytes = dev->d_base + (off - dev->lo);
-                *len = (size_t)n;
-            }
-        } else {
-            rc = orcd_column_get_stream(col, kind, bytes, len);
-        }
+        uint64_t off = 0, n = 0;
+        const int rc = orcd_column_stream_range(col, kind, &off, &n);
         if (rc == ORCD_INVALID_KIND && !required) return ORCD_OK;
         if (rc != ORCD_OK) return rc;
+        if (off < dev->lo || off > dev->hi || n > dev->hi - off) return ORCD_OUT_OF_SPEC;
+        *bytes = dev->d_base + (off - dev->lo);
+        *len = (size_t)n;
         return orcd_column_entry_points(file, col, kind, entries, n_entries);
     }
 };
@@ -1624,15 +1618,6 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
     return rc;
 }
 
-int decode_column_impl(orcd_ctx *c, orcd_file *file, orcd_column *col, int type_kind, unsigned flags,
-                       orcd_column_data *out) {
-    Pending p(c);
-    uint64_t n_values = 0;
-    const ColumnStreams cs{file, col, nullptr};
-    ORCD_TRY(column_validity(c, cs, p, &n_values));
-    return column_values(c, cs, type_kind, flags, p, n_values, false, out);
-}
-
 // Columns of a stripe under construction.
 struct StripeJob {
     orcd_column *col = nullptr;
@@ -1823,21 +1808,12 @@ int orcd_decode_stripe(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
 } ORCD_CATCH
 
 int orcd_decode_column(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
-                       uint32_t column, unsigned flags, orcd_column_data *out) try {
-    if (!c || !file || !footer || !out) return ORCD_INVALID_ARGUMENT;
-    memset(out, 0, sizeof(*out));
-    if (orcd_file_compression(file) != 0) return ORCD_UNSUPPORTED;  // chunk framing is not decoded here
-    if (column >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
-    const int type_kind = orcd_file_type_kind(file, column);
-    orcd_column *col = nullptr;
-    ORCD_TRY(orcd_read_stripe_column(file, stripe, footer, column, &col));
-    DeviceGuard g(c->device);
-    const int rc = decode_column_impl(c, file, col, type_kind, flags, out);
-    (void)hipStreamSynchronize(c->stream);  // the column's bytes were read by asynchronous copies
-    orcd_column_free(col);
-    if (rc != ORCD_OK) memset(out, 0, sizeof(*out));
-    return rc;
-} ORCD_CATCH
+                       uint32_t column, unsigned flags, orcd_column_data *out) {
+    if (!out) return ORCD_INVALID_ARGUMENT;
+    // one column of a stripe is a stripe of one column: the same read (threaded, through pinned
+    // chunks) of the column's region and the same decode from its device copy
+    return orcd_decode_stripe(c, file, stripe, footer, &column, 1, flags, out);
+}
 
 void orcd_column_data_free(orcd_column_data *d) {
     if (!d) return;
