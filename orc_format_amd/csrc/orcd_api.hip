@@ -448,6 +448,18 @@ int guess_entry_points(orcd_ctx *c, const uint8_t *d_stream, size_t len, int is_
     return ORCD_OK;
 }
 
+// How many runs per segment the counting pass stages (0: none, the run table is written by a second
+// walk).  Many segments: by the bytes an average segment holds.  Few segments (a stream without
+// entry points, a small column): every run there can be -- a run takes at least two stream bytes --
+// as long as that stays a modest amount of memory; the walk of such a stream is one lane's serial
+// work (about half a microsecond per run), and staging spares the second one.
+uint32_t pick_staged_cap(uint64_t len, uint32_t n_seg) {
+    if (n_seg >= 64) return staged_runs_cap(len, n_seg);
+    const uint64_t cap = (len / 2 + 64) / 64 * 64;
+    if (cap > 0xFFFFFF00ull || cap * n_seg * sizeof(uint64_t) > (1ull << 30)) return 0;
+    return (uint32_t)cap;
+}
+
 // Builds the run table of one RLE v2 stream that is already on the device.  d_seg_ends (nullable):
 // the end of every segment, for slices of a larger buffer decoded as one stream; seg_table
 // (nullable) receives the segment prefix sums for the caller's own checks.
@@ -469,11 +481,11 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
     const uint64_t *seg_ends = n_entries ? d_seg_ends : nullptr;
-    // With more than a few segments the counting pass keeps the descriptors it parses, and the
-    // run table is then written without a second walk of the header chain.
+    // The counting pass keeps the descriptors it parses, and the run table is then written
+    // without a second walk of the header chain.
     void *staged = nullptr;
-    const uint32_t staged_cap = staged_runs_cap(len, n_seg);
-    if (n_seg >= 64) ORCD_TRY(ensure(c, SLOT_STAGED_RUNS, (size_t)n_seg * staged_cap * sizeof(uint64_t), &staged));
+    const uint32_t staged_cap = pick_staged_cap(len, n_seg);
+    if (staged_cap) ORCD_TRY(ensure(c, SLOT_STAGED_RUNS, (size_t)n_seg * staged_cap * sizeof(uint64_t), &staged));
     ScanResult sr;
     ORCD_TRY(count_and_scan(c, n_seg, num_values, [&](const SegTable &st) {
         return launch_rlev2_count(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, st,
@@ -538,8 +550,8 @@ int byte_rle_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_
     const uint64_t *entries = n_entries ? d_entries : nullptr;
     const uint64_t *seg_ends = n_entries ? d_seg_ends : nullptr;
     void *staged = nullptr;  // as in rlev2_table
-    const uint32_t staged_cap = staged_runs_cap(len, n_seg);
-    if (n_seg >= 64) ORCD_TRY(ensure(c, SLOT_STAGED_RUNS, (size_t)n_seg * staged_cap * sizeof(uint64_t), &staged));
+    const uint32_t staged_cap = pick_staged_cap(len, n_seg);
+    if (staged_cap) ORCD_TRY(ensure(c, SLOT_STAGED_RUNS, (size_t)n_seg * staged_cap * sizeof(uint64_t), &staged));
     ScanResult sr;
     ORCD_TRY(count_and_scan(c, n_seg, num_bytes, [&](const SegTable &st) {
         return launch_byte_rle_count(c->stream, d_stream, len, entries, seg_ends, n_seg, st, (uint64_t *)staged,
