@@ -488,6 +488,9 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
     if (staged_cap) ORCD_TRY(ensure(c, SLOT_STAGED_RUNS, (size_t)n_seg * staged_cap * sizeof(uint64_t), &staged));
     ScanResult sr;
     ORCD_TRY(count_and_scan(c, n_seg, num_values, [&](const SegTable &st) {
+        if (n_seg <= COOP_MAX_SEGMENTS)
+            return launch_rlev2_coop_count(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, st,
+                                           (uint64_t *)staged, staged_cap);
         return launch_rlev2_count(c->stream, d_stream, len, entries, seg_ends, n_seg, is_signed, st,
                                   (uint64_t *)staged, staged_cap);
     }, &sr));

@@ -388,6 +388,146 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
     }
 }
 
+// COUNT for streams of few segments: a wavefront per segment instead of a lane.  One lane parses a
+// header in about half a microsecond, and a segment of thousands of short runs -- or a whole
+// stream that came without entry points -- is thousands of those in a row.  Here the lanes parse,
+// at once, the 64 byte offsets that follow the current header (or, after a run of 64 bytes and
+// more, 64 guesses at that run's stride); the first offset is a real header, and a scalar loop
+// hops from it along the true chain at a readlane per run.  The headers found collect in an LDS
+// ring and are parsed in full 64 at a time, which is also where their descriptors are staged.
+// Writes t.seg_count only; rlev2_publish_kernel turns that into the scan's inputs.
+constexpr uint32_t COOP_RING = 128;
+
+__global__ __launch_bounds__(256) void rlev2_coop_count_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
+    const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
+    uint64_t *__restrict__ staged, uint32_t staged_cap) {
+    __shared__ uint64_t ring_all[4][COOP_RING];
+    uint64_t *ring = ring_all[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seg >= n_seg) return;  // whole wavefront
+    // the segment's bounds, as rlev2_scan_kernel takes them
+    uint64_t pos = (entries && (seg > 0 || seg_ends)) ? entries[seg] : 0;
+    uint64_t end = (entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
+    if (seg_ends) end = seg_ends[seg];
+    const uint64_t limit = seg_ends ? (end < len ? end : len) : len;
+    const bool last_seg = seg + 1 == n_seg;
+    if (pos > len) pos = len;
+    pos = readfirstlane64(pos);
+    end = readfirstlane64(end);
+    uint32_t n_runs = 0, last_len = 0, status = SEG_OK, ring_n = 0;
+    uint64_t n_vals = 0, last_size = 0;
+    if (end > len || end < pos) status = SEG_MISALIGNED;
+    uint64_t *mine = staged ? staged + (uint64_t)seg * staged_cap : nullptr;
+    for (;;) {
+        // ---- find headers until 64 are waiting or the segment ends -----------------------
+        while (status == SEG_OK && pos < end && ring_n < 64) {
+            const bool strided = last_size >= 64;
+            const uint64_t stride = strided ? last_size : 1;
+            const uint64_t p = pos + (uint64_t)lane * stride;
+            const bool inb = p < end;
+            uint32_t st = SEG_OK;
+            uint64_t size = 0;
+            if (inb) {
+                ParsedRun r;
+                st = parse_run(load_window(s, limit, p), s, limit, p, is_signed, r);
+                size = r.run_end - p;
+            }
+            const uint32_t st0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
+            if (st0 != SEG_OK) {  // the header at pos is a real one: the walk stops here
+                status = st0;
+                break;
+            }
+            uint32_t accepted;
+            if (strided) {
+                // offset k * stride is a header if every run before it was `stride` long
+                const uint64_t same = __ballot(inb && st == SEG_OK && size == stride);
+                const uint32_t lead = same == ~0ull ? 64u : (uint32_t)__ffsll((unsigned long long)~same) - 1u;
+                if (lead == 0) {  // the run at pos has another size: it alone is taken
+                    accepted = 1;
+                    last_size = readfirstlane64(size);
+                    if (lane == 0) ring[ring_n] = p;
+                    pos += last_size;
+                } else {
+                    accepted = lead;
+                    if (lane < lead) ring[ring_n + lane] = p;
+                    pos += (uint64_t)lead * stride;
+                }
+            } else {
+                uint64_t chain = 0;
+                uint32_t cur = 0;
+                while (cur < 64) {
+                    if (pos + cur >= end) break;
+                    if (readlane32(st, (int)cur) != SEG_OK) break;  // a real header that does not parse: reported when it is at pos
+                    chain |= 1ull << cur;
+                    last_size = readlane64(size, (int)cur);
+                    if (last_size >= 64 - cur) {  // the next header lies past these 64 offsets
+                        pos += cur + last_size;
+                        cur = 0xFFFFFFFFu;
+                        break;
+                    }
+                    cur += (uint32_t)last_size;
+                }
+                if (cur != 0xFFFFFFFFu) pos += cur;  // stopped inside: at the segment's end or at a bad header
+                accepted = (uint32_t)__popcll((unsigned long long)chain);
+                if ((chain >> lane) & 1) ring[ring_n + (uint32_t)__popcll((unsigned long long)(chain & ((1ull << lane) - 1)))] = p;
+            }
+            ring_n += accepted;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (ring_n == 0) break;
+        // ---- the next (up to) 64 headers in full ------------------------------------------
+        const uint32_t take = ring_n < 64 ? ring_n : 64;
+        uint32_t rlen = 0;
+        if (lane < take) {
+            const uint64_t p = ring[lane];
+            ParsedRun r;
+            (void)parse_run(load_window(s, limit, p), s, limit, p, is_signed, r);  // parsed fine a moment ago
+            rlen = r.len;
+            if (mine && n_runs + lane < staged_cap)
+                mine[n_runs + lane] = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes);
+        }
+        uint32_t sum = rlen;
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        n_vals += sum;
+        last_len = readlane32(rlen, (int)take - 1);
+        n_runs += take;
+        const uint32_t rest = ring_n - take;  // at most 63
+        const uint64_t moved = lane < rest ? ring[take + lane] : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rest) ring[lane] = moved;
+        ring_n = rest;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (status == SEG_OK && pos != end && !last_seg) status = SEG_MISALIGNED;
+    if (lane == 0) {
+        SegCount c;
+        c.n_runs = n_runs;
+        c.last_len = last_len;
+        c.status = status;
+        c.pad = 0;
+        c.n_vals = n_vals;
+        t.seg_count[seg] = c;
+    }
+}
+
+// What rlev2_coop_count_kernel left in t.seg_count, through the workgroup-local scan that the
+// counting kernel proper ends with.
+__global__ __launch_bounds__(SEG_BLOCK) void rlev2_publish_kernel(uint32_t n_seg, SegTable t) {
+    const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
+    SegCount c;
+    c.n_runs = 0;
+    c.last_len = 0;
+    c.status = SEG_OK;
+    c.n_vals = 0;
+    if (seg < n_seg) c = t.seg_count[seg];
+    seg_publish(t, seg, n_seg, c.n_runs, c.last_len, c.status, c.n_vals);
+}
+
 // EMIT for the segments whose descriptors the counting pass staged: a group of lanes per segment,
 // one lane per run (a segment with more runs than lanes takes them a group at a time).  Nothing
 // here waits on the header chain: a run's place follows from a scan of the lengths, and the base /
@@ -1280,6 +1420,15 @@ hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t le
     rlev2_scan_kernel<false><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, seg_ends, n_seg,
                                                           is_signed, t, nullptr, nullptr, nullptr, 0, 0,
                                                           staged, staged_cap, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_rlev2_coop_count(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                   const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
+                                   int is_signed, const SegTable &t, uint64_t *staged, uint32_t staged_cap) {
+    rlev2_coop_count_kernel<<<(n_seg + 3) / 4, 256, 0, st>>>(stream, len, entries, seg_ends, n_seg, is_signed, t,
+                                                             staged, staged_cap);
+    rlev2_publish_kernel<<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(n_seg, t);
     return hipGetLastError();
 }
 
