@@ -123,7 +123,7 @@ hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t le
                               int is_signed, const SegTable &t, uint64_t *staged, uint32_t staged_cap);
 // The counting pass for streams of at most COOP_MAX_SEGMENTS segments: a wavefront per segment
 // (see rlev2_coop_count_kernel); same results in `t`, same staging.
-constexpr uint32_t COOP_MAX_SEGMENTS = 4096;
+constexpr uint32_t COOP_MAX_SEGMENTS = 16384;
 hipError_t launch_rlev2_coop_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                                    const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                                    int is_signed, const SegTable &t, uint64_t *staged, uint32_t staged_cap);

@@ -716,6 +716,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void block_totals_scan_kernel(SegTabl
             tt.error = ORCD_OUT_OF_SPEC;  // the stream ends before num_values values
         }
         *t.totals = tt;
+        if (t.host_totals) {
+            volatile ScanTotals *h = t.host_totals;
+            h->total_vals = tt.total_vals;
+            h->total_runs = tt.total_runs;
+            h->error = tt.error;
+            h->error_seg = tt.error_seg;
+            h->max_seg_runs = tt.max_seg_runs;
+            __threadfence_system();
+            h->pad = t.host_stamp;
+        }
     }
 }
 

@@ -36,6 +36,11 @@ struct SegTable {
     BlockTotals *blk;       // [n_blocks]
     BlockOffset *boff;      // [n_blocks]
     ScanTotals *totals;
+    // (nullable) the same totals once more, in host memory the device can write, stamped with
+    // `host_stamp` in ScanTotals::pad after everything else: the host watches for the stamp
+    // instead of queueing a copy and waiting for the stream
+    ScanTotals *host_totals;
+    uint32_t host_stamp;
 };
 
 __device__ __forceinline__ uint64_t seg_shfl_up64(uint64_t v, unsigned d) {
