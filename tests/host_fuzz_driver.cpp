@@ -53,6 +53,24 @@ static int walk(const std::vector<uint8_t> &image) {
                     checksum += entries[0] + entries[n_entries - 1];
             }
             orcd_column_free(col);
+            // the handle without bytes: region, stream places, a positioned read of each place
+            orcd_column *bare = nullptr;
+            if (orcd_stripe_column_open(f, stripe, ft, column, &bare) != ORCD_OK) continue;
+            uint64_t off = 0, n = 0;
+            if (orcd_column_region(bare, &off, &n) == ORCD_OK) checksum += off + n;
+            for (int k = 0; k < 8; k++) {
+                if (orcd_column_stream_range(bare, k, &off, &n) != ORCD_OK || n == 0 || n > (1u << 20)) continue;
+                std::vector<uint8_t> got(n);
+                if (orcd_file_read_at(f, si.offset + off, n, got.data()) == ORCD_OK) checksum += got[0] + got[n - 1];
+                const uint64_t *entries;
+                size_t n_entries;
+                if (orcd_column_entry_points(f, bare, k, &entries, &n_entries) == ORCD_OK && n_entries)
+                    checksum += entries[0] + entries[n_entries - 1];
+            }
+            const uint8_t *none;
+            size_t none_len;
+            if (orcd_column_get_stream(bare, 1, &none, &none_len) == ORCD_OK) return 99;  // it has no bytes
+            orcd_column_free(bare);
         }
         orcd_stripe_footer_free(ft);
     }
