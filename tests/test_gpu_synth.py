@@ -187,3 +187,28 @@ def test_large_pageable_results_of_other_decoders():
                                      length_entry_points=lentries.cpu().numpy().astype(np.uint64))
     want_off = np.concatenate([[0], np.cumsum(lengths.view(-1).cpu().numpy())])
     assert (offsets == want_off).all() and got.tobytes() == data.tobytes()
+
+
+def test_decode_on_the_callers_stream():
+    """orcd_ctx_set_stream: the context's work is queued on a stream of the caller's -- after
+    what the caller queued there before (the generator's kernels, no synchronisation in between)
+    and before what it queues afterwards."""
+    import torch
+    from bench_util import synth
+    from orc_format_amd import Context
+    ctx = Context(0)
+    side = torch.cuda.Stream()
+    ctx.set_stream(side.cuda_stream)
+    try:
+        with torch.cuda.stream(side):
+            for seed in (1, 2, 3):
+                stream, entries, values = synth.delta_monotonic(300, seed=seed, device="cuda", width=10)
+                n = 300 * 512
+                out = torch.empty(n, dtype=torch.int64, device="cuda")
+                ctx.rlev2_device(stream.data_ptr(), stream.numel(), n, True, out.data_ptr(),
+                                 entries.data_ptr(), entries.numel())
+                doubled = out * 2          # queued behind the decode on the same stream
+                side.synchronize()
+                assert torch.equal(out, values) and torch.equal(doubled, values * 2)
+    finally:
+        ctx.set_stream(None)
