@@ -58,21 +58,32 @@ def sum_over_ranks(value, dist=None, device=None):
 
 
 def decode_file_shard(ctx, metadata, rank, world_size, columns=None, row_aligned=True,
-                      check_utf8=True):
+                      check_utf8=True, extra_contexts=()):
     """The stripes of an open file that fall to `rank`, decoded on that rank's context (one
     orcd_decode_stripe call per stripe).  Returns a list of (stripe index, first row of the stripe
     in the file, [column dicts as Context.decode_stripe returns them]); the ranks' lists together
     hold every stripe once, and the first rows say where each piece belongs -- no exchange is
     needed to assemble the table (reference: the stripe loop of tests/it/main.rs:8-24, which this
-    spreads over ranks)."""
+    spreads over ranks).
+
+    extra_contexts: more contexts on the same GPU; the rank's stripes are then dealt to one host
+    thread per context, so that one stripe's read and copy overlap another's decode."""
     from . import read
     if columns is None:
         columns = list(range(1, len(metadata.types)))
     first_rows = row_offsets([s.number_of_rows for s in metadata.stripes])
-    out = []
-    for stripe in stripes_of_rank(metadata, rank, world_size):
+    mine = stripes_of_rank(metadata, rank, world_size)
+    contexts = [ctx] + list(extra_contexts)
+
+    def one(job):
+        k, stripe = job
         footer = read.read_stripe_footer(metadata, stripe)
-        out.append((stripe, first_rows[stripe],
-                    ctx.decode_stripe(metadata, stripe, footer, columns, check_utf8=check_utf8,
-                                      row_aligned=row_aligned)))
-    return out
+        return (stripe, first_rows[stripe],
+                contexts[k].decode_stripe(metadata, stripe, footer, columns, check_utf8=check_utf8,
+                                          row_aligned=row_aligned))
+    jobs = [(i % len(contexts), stripe) for i, stripe in enumerate(mine)]
+    if len(contexts) == 1:
+        return [one(j) for j in jobs]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(len(contexts)) as pool:
+        return list(pool.map(one, jobs))

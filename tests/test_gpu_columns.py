@@ -277,8 +277,12 @@ def test_file_sharded_over_ranks_equals_pyarrow(tmp_path):
     b = np.zeros(rows, dtype=np.int64)
     s = [None] * rows
     seen = []
+    from orc_format_amd import Context
+    second = Context(0)
     for rank in range(2):
-        for stripe, first, cols in shard.decode_file_shard(ctx, md, rank, 2):
+        # rank 1 also spreads its stripes over two contexts / host threads
+        for stripe, first, cols in shard.decode_file_shard(ctx, md, rank, 2,
+                                                           extra_contexts=[second] if rank else ()):
             seen.append(stripe)
             n = cols[0]["validity"].size
             a[first:first + n] = cols[0]["values"]
