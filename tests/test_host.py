@@ -30,6 +30,47 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
 
 
+def test_rust_binding_declares_the_header():
+    """rust/src/ffi.rs (the binding a maintainer of the crate would add) names every entry point,
+    status code and flag of include/orcd.h with the same value, and every argument of every
+    function."""
+    with open(os.path.join(ROOT, "include", "orcd.h")) as f:
+        header = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    with open(os.path.join(ROOT, "rust", "src", "ffi.rs")) as f:
+        rust = re.sub(r"//.*", "", f.read())
+    c_args = {}
+    for name, args in re.findall(r"\b(orcd_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header):
+        names = [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", a)[-1] for a in args.split(",") if a.strip()]
+        c_args[name] = names
+    r_args = {}
+    for name, args in re.findall(r"\bfn (orcd_[a-z0-9_]+)\s*\(([^)]*)\)", rust):
+        r_args[name] = [a.split(":")[0].strip() for a in args.split(",") if a.strip()]
+    assert set(c_args) == set(r_args), set(c_args) ^ set(r_args)
+    for name in c_args:
+        assert c_args[name] == r_args[name], (name, c_args[name], r_args[name])
+    enums = {}
+    for body in re.findall(r"enum\s*\{(.*?)\}", header, flags=re.S):
+        for name, value in re.findall(r"(ORCD_[A-Z0-9_]+)\s*=\s*(\d+)", body):
+            enums[name] = int(value)
+    consts = {n: int(v) for n, v in re.findall(r"pub const (ORCD_[A-Z0-9_]+): \w+ = (\d+);", rust)}
+    assert enums == consts, set(enums.items()) ^ set(consts.items())
+    # the structures that cross the boundary: same fields in the same order
+    c_structs = {}
+    for body, name in re.findall(r"typedef struct\s*\{(.*?)\}\s*(orcd_[a-z0-9_]+)\s*;", header, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            parts = [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", p) for p in decl.split(",")]
+            fields += [p[-1] for p in parts if p]
+        c_structs[name] = fields
+    r_structs = {}
+    for name, body in re.findall(r"pub struct (orcd_[a-z0-9_]+)\s*\{(.*?)\}", rust, flags=re.S):
+        fields = re.findall(r"pub ([a-z0-9_]+)\s*:", body)
+        if fields:
+            r_structs[name] = fields
+    assert len(c_structs) >= 5
+    assert c_structs == r_structs, (c_structs, r_structs)
+
+
 def test_strerror():
     assert N.lib().orcd_strerror(1) == b"out of spec"
     assert N.lib().orcd_strerror(0) == b"ok"
