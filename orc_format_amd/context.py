@@ -48,6 +48,7 @@ class Context:
         self._lib = N.lib()
         self._h = C.c_void_p()
         check(self._lib.orcd_ctx_create(device, C.byref(self._h)))
+        self.caller_stream = 0
         self.device = device
 
     def close(self):
@@ -73,6 +74,7 @@ class Context:
 
     def set_stream(self, hip_stream):
         check(self._lib.orcd_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)), self._h)
+        self.caller_stream = hip_stream or 0  # 0: the context's own stream
 
     def synchronize(self):
         check(self._lib.orcd_ctx_synchronize(self._h), self._h)

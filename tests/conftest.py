@@ -24,3 +24,27 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def inputs_ready_before_device_calls(request, monkeypatch):
+    """A context decodes on a stream of its own (unless it was given the caller's), which is not
+    ordered against the stream torch prepares the tests' inputs on (fills, clones, generators):
+    for the GPU tests every device-pointer call of a context on its own stream first waits for the
+    device, the way a caller of the C ABI must before it hands over buffers other streams wrote."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    from orc_format_amd import context
+
+    def waiting(method):
+        def call(self, *args, **kwargs):
+            if not self.caller_stream:
+                torch.cuda.synchronize()
+            return method(self, *args, **kwargs)
+        return call
+    for name in dir(context.Context):
+        if name.endswith("_device"):
+            monkeypatch.setattr(context.Context, name, waiting(getattr(context.Context, name)))
+    yield
