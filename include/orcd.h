@@ -17,6 +17,10 @@
  *    a decode call returns once its status is final (all validation happens in the header-scan
  *    kernels, which the call waits for).  With ORCD_OUT_DEVICE the value kernels may still be
  *    running on the stream when the call returns; with host outputs the call is synchronous.
+ *  - The context's stream is not ordered against any other stream (it is created non-blocking):
+ *    device buffers that work on another stream writes or still reads -- inputs being prepared,
+ *    outputs being filled or consumed -- must be finished with before the call, or the context
+ *    must be put on that stream (orcd_ctx_set_stream).
  *  - Decoding stops after `num_values` values; trailing stream bytes are ignored.
  */
 #ifndef ORCD_H
