@@ -149,3 +149,27 @@ def test_four_billion_booleans(ctx):
     assert int(ones) == want_ones
     del stream, entries, decoded, out
     _free()
+
+
+@pytest.mark.parametrize("runs_per_entry", [64, 512])
+def test_half_a_billion_values_in_short_runs(ctx, runs_per_entry):
+    """2.5*10^7 runs of ShortRepeat (3..10 copies, rle_v2.rs:283-329) and Direct width 4 (1..64
+    values) -- about 25 runs under every 512 values, the many-runs path of the value kernel --
+    with an entry point every 64 or every 512 runs; whole and stopped at an entry point's value."""
+    import torch
+    from bench_util import synth
+    stream, entries, expect, entry_values = synth.mixed_short_runs(
+        500_000_000 // 20, runs_per_entry=runs_per_entry, device="cuda")
+    n = int(expect.numel())
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    cut = int(entry_values[entry_values.numel() // 2].item()) + 3
+    for count in (n, cut):
+        out.fill_(-7)
+        torch.cuda.synchronize()
+        ctx.rlev2_device(stream.data_ptr(), stream.numel(), count, False, out.data_ptr(),
+                         entries.data_ptr(), entries.numel())
+        ctx.synchronize()
+        assert torch.equal(out[:count], expect[:count])
+        assert bool((out[count:] == -7).all())
+    del stream, entries, expect, entry_values, out
+    _free()
