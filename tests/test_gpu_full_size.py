@@ -173,3 +173,66 @@ def test_half_a_billion_values_in_short_runs(ctx, runs_per_entry):
         assert bool((out[count:] == -7).all())
     del stream, entries, expect, entry_values, out
     _free()
+
+
+def test_more_than_2_to_32_values(ctx):
+    """A column with more values than 32 bits count: 8.5*10^6 Delta runs of 512 values with a fixed
+    delta (width 0: header, base, delta base and nothing else, rle_v2.rs:184-281), 4 stream bytes
+    each, 35 GB decoded.  Every run is 5, 8, 11, ...; the last values sit past index 2^32."""
+    import torch
+    n_runs = 8_500_000
+    n = n_runs * 512
+    assert n > (1 << 32)
+    run = torch.tensor([0xC1, 0xFF, 0x0A, 0x06], dtype=torch.uint8, device="cuda")  # zigzag(5), zigzag(3)
+    stream = run.repeat(n_runs)
+    entries = torch.arange(0, n_runs, 32, dtype=torch.int64, device="cuda") * 4
+    want_run = torch.arange(512, dtype=torch.int64, device="cuda") * 3 + 5
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    for use in (True, False):
+        out.fill_(-7)
+        torch.cuda.synchronize()
+        ctx.rlev2_device(stream.data_ptr(), stream.numel(), n, True, out.data_ptr(),
+                         entries.data_ptr() if use else 0, entries.numel() if use else 0)
+        ctx.synchronize()
+        rows = out.view(n_runs, 512)
+        step = 1 << 19
+        for a in range(0, n_runs, step):
+            assert bool((rows[a:a + step] == want_run).all()), (use, a)
+    del stream, entries, out, rows
+    _free()
+
+
+def test_more_than_2_to_32_booleans(ctx):
+    """5*10^9 + 3 booleans from 4.9*10^6 byte-RLE runs of 130 bytes (boolean_rle.rs:40-62; the run
+    emits header + 3 copies), alternately 0xff and 0x0f: bytes, bitmap and the count of ones."""
+    import torch
+    n_bits = 5_000_000_003
+    n_bytes = (n_bits + 7) // 8
+    n_runs = (n_bytes + 129) // 130
+    n_runs += n_runs & 1
+    stream = torch.tensor([0x7F, 0xFF, 0x7F, 0x0F], dtype=torch.uint8, device="cuda").repeat(n_runs // 2)
+    entries = torch.arange(0, n_runs, 50, dtype=torch.int64, device="cuda") * 2
+    out = torch.empty(n_bits, dtype=torch.uint8, device="cuda")
+    bitmap = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ones = ctx.boolean_device(stream.data_ptr(), stream.numel(), n_bits, out.data_ptr(),
+                              bitmap.data_ptr(), entries.data_ptr(), entries.numel())
+    ctx.synchronize()
+    # decoded byte k belongs to run k // 130; even runs are 0xff, odd runs 0x0f (0,0,0,0,1,1,1,1)
+    want_ones = 0
+    step = 130 * 2 * (1 << 18)  # whole pairs of runs
+    pair = torch.cat([torch.ones(130 * 8, dtype=torch.uint8, device="cuda"),
+                      torch.tensor([0, 0, 0, 0, 1, 1, 1, 1], dtype=torch.uint8, device="cuda").repeat(130)])
+    pair_bm = torch.cat([torch.full((130,), 0xFF, dtype=torch.uint8, device="cuda"),
+                         torch.full((130,), 0xF0, dtype=torch.uint8, device="cuda")])  # least significant bit first
+    for a in range(0, n_bytes, step):
+        b = min(n_bytes, a + step)
+        bits = min(n_bits, b * 8) - a * 8
+        want = pair.repeat((b - a + 259) // 260)[:bits]
+        assert torch.equal(out[a * 8:a * 8 + bits], want), a
+        want_ones += int(want.sum(dtype=torch.int64).item())
+        whole = bits // 8
+        assert torch.equal(bitmap[a:a + whole], pair_bm.repeat((b - a + 259) // 260)[:whole]), a
+    assert int(ones) == want_ones
+    del stream, entries, out, bitmap
+    _free()
