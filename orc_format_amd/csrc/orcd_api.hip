@@ -1057,7 +1057,7 @@ int orcd_boolean_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t n
     ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t),
                       in_dev && !(flags & ORCD_ENTRIES_HOST), &d_entries));
     void *flagbuf;
-    ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flagbuf));
+    ORCD_TRY(ensure(c, SLOT_FLAGS, BOOL_COUNT_BYTES, &flagbuf));
     ByteRleTable t;
     ORCD_TRY(byte_rle_table(c, (const uint8_t *)d_stream, len, n_bytes, (const uint64_t *)d_entries,
                             n_entries, &t));
@@ -1074,7 +1074,6 @@ int orcd_boolean_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t n
         }
     }
     uint64_t *d_count = set_bits ? (uint64_t *)flagbuf : nullptr;
-    if (d_count) HIP_TRY(c, hipMemsetAsync(d_count, 0, sizeof(uint64_t), c->stream));
     // the run table expands straight into values: no packed intermediate
     if (d_bytes || d_bitmap || d_count)
         HIP_TRY(c, launch_bool_expand(c->stream, (const uint8_t *)d_stream, len, t.runs, t.win_first,

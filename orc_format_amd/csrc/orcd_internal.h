@@ -195,7 +195,9 @@ hipError_t launch_byte_rle_expand(hipStream_t st, const uint8_t *stream, uint64_
                                   const ByteRun *runs, const uint32_t *win_first, uint32_t n_win_slots,
                                   uint32_t n_runs, uint64_t num_bytes, uint8_t *out);
 // run table -> booleans in one pass: one byte per value, and/or an LSB-first bitmap, plus the
-// number of ones (set_bits must be zeroed beforehand)
+// number of ones: set_bits (nullable) is BOOL_COUNT_BYTES of device memory whose first word holds
+// the count when the work queued here is done
+constexpr size_t BOOL_COUNT_BYTES = 8192;
 hipError_t launch_bool_expand(hipStream_t st, const uint8_t *stream, uint64_t len,
                               const ByteRun *runs, const uint32_t *win_first, uint32_t n_win_slots,
                               uint32_t n_runs, uint64_t num_bits, uint8_t *out_bytes,
