@@ -141,9 +141,11 @@ def main():
     for _ in range(args.steps):
         step()
         for p in phase_ms:  # HIP events recorded on the context's stream around each phase
-            phase_ms[p] += ctx.phase_ms(p)
+            phase_ms[p] += max(0.0, ctx.phase_ms(p))  # negative: the phase did not run
     barrier()
     elapsed = time.perf_counter() - t0
+    # which kernel expanded the values: the single-launch one for regular columns, or the general one
+    value_kernel = "rlev2_strided_values_kernel" if ctx.last_path() == 1 else "rlev2_values_kernel<0>"
     from orc_format_amd import shard
     elapsed = shard.max_over_ranks(elapsed, dist, device=REDUCE_DEVICE)
 
@@ -174,7 +176,7 @@ def main():
         "config": {"workload": "%s: %d rows per GPU per step; %s" % (args.workload, rows, desc),
                    "rows_per_gpu": rows, "stream_bytes_per_gpu": stream_bytes,
                    "entry_points_per_gpu": int(entries.numel()), "parallelism": "stripe-sharded x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "rlev2_values_kernel",
+        "roofline": {"bound": "hbm", "kernel": value_kernel,
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": algo_bytes,
@@ -190,7 +192,7 @@ def main():
     # inside this process: they are taken from the newest committed rocprofv3 summary of this same
     # command and workload (separate FETCH_SIZE / WRITE_SIZE passes, see profiles/README.md).
     if full_size:
-        attach_traffic(result, args.workload, "rlev2_values_kernel")
+        attach_traffic(result, args.workload, value_kernel)
 
     if args.end_to_end:
         result["end_to_end"] = end_to_end(args, ctx, stream, entries, expect, rows, signed, torch)
@@ -215,7 +217,9 @@ def attach_traffic(result, workload, kernel):
     with open(found[-1]) as f:
         prof = json.load(f)
     for name, k in prof.get("kernels", {}).items():
-        if kernel in name and "hbm_bytes_per_launch" in k:
+        # exact kernel, template arguments included ("void orcd::string_bytes_kernel<true, true>")
+        bare = name.replace("void ", "").replace("orcd::", "").strip()
+        if bare == kernel and "hbm_bytes_per_launch" in k:
             result["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
             result["roofline"]["traffic_source"] = os.path.relpath(found[-1], ROOT)
             return
@@ -291,7 +295,7 @@ def bench_strings(args, rank, world, local_rank, dist, desc, torch, np):
                    "strings_per_gpu": n, "data_bytes_per_gpu": total,
                    "length_stream_bytes_per_gpu": int(lstream.numel()),
                    "parallelism": "stripe-sharded x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "string_bytes_kernel", "achieved": round(achieved, 1),
+        "roofline": {"bound": "hbm", "kernel": "string_bytes_kernel<true, true>", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                      "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
                      "avg_launch_ms": round(k_ms, 4)},
@@ -302,7 +306,7 @@ def bench_strings(args, rank, world, local_rank, dist, desc, torch, np):
         "decoded_frac_of_hbm_peak": round(value / world / HBM_PEAK_GBPS, 4),
     }
     if n == DEFAULT_ROWS["strings_w6"] - DEFAULT_ROWS["strings_w6"] % 512:
-        attach_traffic(result, args.workload, "string_bytes_kernel")
+        attach_traffic(result, args.workload, "string_bytes_kernel<true, true>")
     # Variant reported separately: DATA left in place (the column is offsets into the stripe's own
     # buffer), i.e. offsets + validation only.
     offsets.zero_()

@@ -89,6 +89,10 @@ class Context:
     def phase_ms(self, phase):
         return float(self._lib.orcd_ctx_phase_ms(self._h, phase))
 
+    def last_path(self):
+        """0: the last RLE v2 decode took the general path, 1: the strided single-launch one."""
+        return int(self._lib.orcd_ctx_last_path(self._h))
+
     # ---- host-buffer calls ------------------------------------------------------------------
     def rlev2(self, stream, num_values, signed, entry_points=None):
         s = _host_u8(stream)

@@ -51,6 +51,7 @@ enum Slot {
     SLOT_FLAGS,
     SLOT_TMP,
     SLOT_STAGED_RUNS,
+    SLOT_SPEC_FLAG,    // the word a speculative launch raises when its guess about the stream is wrong
     N_SLOTS
 };
 
@@ -198,6 +199,11 @@ struct orcd_ctx {
     BlockCache dev_cache{false};   // device memory
     BlockCache host_cache{true};   // pinned host memory: host results of the column calls
     hipError_t last_hip = hipSuccess;
+    // Speculative decode of regular columns (try_strided): which way the last RLE v2 call went
+    // (ORCD_PATH_*), and how many eligible calls skip the attempt after it failed twice in a row.
+    int last_path = 0;
+    uint32_t spec_fail_streak = 0, spec_skip = 0;
+    bool spec_flag_clean = false;  // the device word of SLOT_SPEC_FLAG is known to be zero
 };
 
 namespace {
@@ -384,6 +390,32 @@ struct ScanResult {
     ScanTotals totals;
 };
 
+// Waits until the kernel that writes the pinned totals has stamped them with `stamp`: the host
+// watches the stamp for a while (a queued copy and a wait for the stream cost 10-15 microseconds
+// more than the kernels they wait for) before it falls back to waiting for the stream.
+// d_totals (nullable): the device copy of the totals, read when the stamp never came.
+int wait_totals_stamp(orcd_ctx *c, uint32_t stamp, const void *d_totals) {
+    volatile ScanTotals *h = c->h_totals;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (uint32_t spins = 0; !(seen = h->pad == stamp); spins++) {
+        if ((spins & 255) == 255 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300))
+            break;
+    }
+    if (!seen) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (h->pad != stamp) {  // the kernel did not reach its end: read what the device holds
+            if (!d_totals) return ORCD_HIP_ERROR;
+            HIP_TRY(c, hipMemcpy(c->h_totals, d_totals, sizeof(ScanTotals), hipMemcpyDeviceToHost));
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return ORCD_OK;
+}
+
+uint32_t next_stamp(orcd_ctx *c) { return ++c->totals_stamp ? c->totals_stamp : ++c->totals_stamp; }  // never 0
+
 // Header count + prefix sums + read-back of the totals (the one host sync of a decode).
 template <typename CountFn>
 int count_and_scan(orcd_ctx *c, uint32_t n_seg, uint64_t num_values, CountFn count, ScanResult *res) {
@@ -400,29 +432,12 @@ int count_and_scan(orcd_ctx *c, uint32_t n_seg, uint64_t num_values, CountFn cou
     t.blk = (BlockTotals *)blk;
     t.boff = (BlockOffset *)boff;
     t.totals = (ScanTotals *)totals;
-    // The scan kernel writes the totals straight into host memory and stamps them; the host
-    // watches for the stamp for a while (a queued copy and a wait for the stream cost 10-15
-    // microseconds more than the kernels they wait for) before it falls back to waiting.
+    // The scan kernel writes the totals straight into host memory and stamps them.
     t.host_totals = c->h_totals;
-    t.host_stamp = ++c->totals_stamp ? c->totals_stamp : ++c->totals_stamp;  // never 0
+    t.host_stamp = next_stamp(c);
     HIP_TRY(c, count(t));
     HIP_TRY(c, launch_block_totals_scan(c->stream, t, n_blocks, num_values));
-    {
-        volatile ScanTotals *h = c->h_totals;
-        const auto t0 = std::chrono::steady_clock::now();
-        bool seen = false;
-        for (uint32_t spins = 0; !(seen = h->pad == t.host_stamp); spins++) {
-            if ((spins & 255) == 255 &&
-                std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300))
-                break;
-        }
-        if (!seen) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (h->pad != t.host_stamp)  // the kernel did not reach its end: read what the device holds
-                HIP_TRY(c, hipMemcpy(c->h_totals, totals, sizeof(ScanTotals), hipMemcpyDeviceToHost));
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-    }
+    ORCD_TRY(wait_totals_stamp(c, t.host_stamp, totals));
     res->totals = *c->h_totals;
     return ORCD_OK;
 }
@@ -548,8 +563,61 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
 }
 
 // RLE v2 decode with device-side input and output.
+// The regular column -- every 512 values one Direct run, equally many equal-sized runs between two
+// entry points -- decoded by one launch with no header scan in front of it (see
+// rlev2_strided_values_kernel); *done says whether that worked out.  Whether a stream is like that
+// is only known afterwards: a failed attempt costs a few microseconds (its wavefronts leave as soon
+// as one has raised the flag), and after two in a row the next SPEC_BACKOFF eligible calls go
+// straight to the general path.
+constexpr size_t SPEC_MIN_VALUES = 8 * WINDOW;
+constexpr uint32_t SPEC_BACKOFF = 16;
+
+int try_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
+                const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done) {
+    *done = false;
+    if (num_values < SPEC_MIN_VALUES || (((uintptr_t)d_out) & 15) || n_entries > 0xFFFFFFFFull) return ORCD_OK;
+    const uint64_t n_win = (num_values + WINDOW - 1) >> WINDOW_SHIFT;
+    const uint64_t n_seg = n_entries ? n_entries : 1;
+    if (n_win > 0xFFFFFFFFull || n_seg > n_win || len < n_win * 3) return ORCD_OK;
+    if (c->spec_skip) {
+        c->spec_skip--;
+        return ORCD_OK;
+    }
+    // the flag word is zero between launches: the publishing kernel leaves it so
+    void *flag;
+    ORCD_TRY(ensure(c, SLOT_SPEC_FLAG, 256, &flag));
+    if (!c->spec_flag_clean) {
+        HIP_TRY(c, hipMemsetAsync(flag, 0, 256, c->stream));
+        c->spec_flag_clean = true;
+    }
+    const uint32_t stamp = next_stamp(c);
+    HIP_TRY(c, launch_rlev2_strided_values(c->stream, d_stream, len, n_entries ? d_entries : nullptr,
+                                           (uint32_t)n_seg, (uint32_t)n_win, num_values, is_signed, d_out,
+                                           (uint32_t *)flag, c->h_totals, stamp));
+    mark(c, 3);  // (phases 1 and 2, header count and run table, did not run)
+    const int rc = wait_totals_stamp(c, stamp, nullptr);
+    if (rc != ORCD_OK) {
+        c->spec_flag_clean = false;
+        return rc;
+    }
+    if (c->h_totals->error == 0) {
+        *done = true;
+        c->spec_fail_streak = 0;
+    } else if (++c->spec_fail_streak >= 2) {
+        c->spec_skip = SPEC_BACKOFF;
+    }
+    return ORCD_OK;
+}
+
 int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
                  const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out) {
+    bool done = false;
+    c->last_path = ORCD_PATH_GENERAL;
+    ORCD_TRY(try_strided(c, d_stream, len, num_values, d_entries, n_entries, is_signed, d_out, &done));
+    if (done) {
+        c->last_path = ORCD_PATH_STRIDED;
+        return ORCD_OK;
+    }
     Rlev2Table t;
     ORCD_TRY(rlev2_table(c, d_stream, len, num_values, d_entries, n_entries, is_signed, &t));
     HIP_TRY(c, launch_rlev2_values(c->stream, t, d_out));
@@ -744,9 +812,10 @@ float orcd_ctx_phase_ms(orcd_ctx *c, int phase) {
     while (last > 0 && !c->ev_valid[last]) last--;
     if (!c->ev_valid[0] || last == 0) return -1.0f;
     int a = 0, b = last;
-    if (phase > 0) {
-        if (!c->ev_valid[phase] || !c->ev_valid[phase - 1]) return -1.0f;
+    if (phase > 0) {  // from the nearest earlier event that was recorded (a phase that did not run has none)
+        if (!c->ev_valid[phase]) return -1.0f;
         a = phase - 1;
+        while (a > 0 && !c->ev_valid[a]) a--;
         b = phase;
     }
     if (hipEventSynchronize(c->ev[b]) != hipSuccess) return -1.0f;
@@ -756,6 +825,8 @@ float orcd_ctx_phase_ms(orcd_ctx *c, int phase) {
 }
 
 float orcd_ctx_last_elapsed_ms(orcd_ctx *c) { return orcd_ctx_phase_ms(c, 0); }
+
+int orcd_ctx_last_path(orcd_ctx *c) { return c ? c->last_path : -1; }
 
 const char *orcd_ctx_last_hip_error(orcd_ctx *c) {
     return c ? hipGetErrorString(c->last_hip) : "no context";

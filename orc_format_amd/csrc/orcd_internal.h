@@ -167,6 +167,15 @@ struct Rlev2Table {
     int is_signed;
 };
 hipError_t launch_rlev2_values(hipStream_t st, const Rlev2Table &t, int64_t *out);
+// Value expansion without a header scan, for the column whose every window of 512 values is one
+// Direct run of 512 values with equally many equal-sized runs between two entry points (see
+// rlev2_strided_values_kernel).  *flag, zero beforehand, is raised when the stream is not like
+// that; when the work is done it is copied to host_totals->error and zeroed again, and
+// host_totals->pad is stamped.  `out` must be 16-byte aligned.
+hipError_t launch_rlev2_strided_values(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                       const uint64_t *entries, uint32_t n_seg, uint32_t n_win,
+                                       uint64_t num_values, int is_signed, int64_t *out, uint32_t *flag,
+                                       ScanTotals *host_totals, uint32_t stamp);
 // The same expansion, reduced: group_sums[g] = saturating sum of the values of the runs that
 // start in the g-th window of 512 values (bit 2 of *flags is raised when a PatchedBase run was
 // met: its patches are not in the sums) ...

@@ -1420,6 +1420,143 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// K3 without K1/K2 for the regular column: every window of 512 values is one Direct run of 512
+// values, and the runs between two entry points all have one size.  Then nothing about a run has to
+// be looked up: the segment of window g is g / R (R runs per segment), the run's size S is the
+// distance to the next entry point divided by R, its header sits at entry + k * S and its width is
+// (S - 2) / 64.  Each wavefront checks the one thing this rests on -- that the two header bytes in
+// front of the payload it stages say "Direct, that width, 512 values" -- and by induction over k
+// (the run at the entry point is real, a real run of S bytes ends where the next one starts, the
+// R-th ends at the next entry point) the headers are the ones a walk of the chain would find
+// (rle_v2.rs:135-157, 480-514).  Any deviation raises *flag and the caller decodes the stream the
+// general way; what was written until then is overwritten.
+// The stream's last window goes through the general single-run code: its run may be of any kind
+// and length (at least the values still wanted).
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t code_from_width(uint32_t w) {
+    if (w >= 1 && w <= 24) return w - 1;
+    if (w <= 32) return (w & 1) || w < 26 ? 0xFFu : 24 + (w - 26) / 2;
+    if (w <= 64) return (w & 7) ? 0xFFu : 28 + (w - 40) / 8;
+    return 0xFFu;
+}
+
+__global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries, uint32_t n_seg,
+    uint32_t n_win, uint64_t num_values, int is_signed, int64_t *__restrict__ out,
+    uint32_t *__restrict__ flag) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[VAL_WAVES][STAGE_WORDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t wg = blockIdx.x;  // XCD-contiguous remap, as in rlev2_values_kernel
+    {
+        const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = wg % 8;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
+    }
+    const uint32_t g = wg * VAL_WAVES + wave;
+    if (g >= n_win) return;
+    // somebody found the column irregular: the rest of this launch is wasted work
+    if (__builtin_amdgcn_readfirstlane(*(const volatile uint32_t *)flag)) return;
+    WaveOf<MODE_VALUES> wv;
+    wv.s = s;
+    wv.lds = stage[wave];
+    wv.out = out;
+    wv.num_values = num_values;
+    wv.len = len;
+    wv.lane = threadIdx.x & 63;
+    wv.is_signed = is_signed;
+    wv.out_aligned = true;  // the launcher insists
+    wv.acc = 0;
+    wv.saw_patched = 0;
+    auto fail = [&]() {
+        if (wv.lane == 0) atomicOr(flag, 1u);
+    };
+    // How many runs lie between two entry points: the distance from the stream's start to its
+    // second entry point over the size of the first run, which must be a Direct run of 512 values
+    // like all the others (two bytes that every wavefront finds in cache).  All segments but the
+    // last hold that many windows, the last one the rest (at least one).
+    uint32_t runs_per_seg = n_win;
+    if (n_seg > 1) {
+        const uint64_t d0 = readfirstlane64(entries[1]);
+        if (len < 2 || d0 > 0xFFFFFFFFull) return fail();
+        const uint32_t h0 = __builtin_amdgcn_readfirstlane((uint32_t)s[0]);
+        const uint32_t h1 = __builtin_amdgcn_readfirstlane((uint32_t)s[1]);
+        if ((h0 >> 6) != KIND_DIRECT || (((h0 & 1u) << 8) | h1) != 511u) return fail();
+        const uint32_t s0 = 2u + 64u * width_from_code((h0 >> 1) & 31u);
+        runs_per_seg = (uint32_t)d0 / s0;
+        if (runs_per_seg * s0 != (uint32_t)d0 || runs_per_seg == 0 ||
+            (uint64_t)runs_per_seg * (n_seg - 1) >= n_win)
+            return fail();
+    }
+    uint32_t seg = g / runs_per_seg;
+    if (seg >= n_seg) seg = n_seg - 1;  // the last segment holds whatever is left
+    const uint32_t k = g - seg * runs_per_seg;
+    const uint64_t e0 = (seg && entries) ? readfirstlane64(entries[seg]) : 0;
+    if (e0 >= len) return fail();
+    uint64_t size;
+    if (seg + 1 < n_seg) {
+        const uint64_t e1 = readfirstlane64(entries[seg + 1]);
+        if (e1 <= e0 || e1 - e0 > 0xFFFFFFFFull) return fail();
+        const uint32_t d = (uint32_t)(e1 - e0);
+        const uint32_t q = d / runs_per_seg;
+        if (q * runs_per_seg != d) return fail();
+        size = q;
+    } else {
+        // no entry point follows the last segment: the size of its first run
+        ParsedRun r;
+        if (parse_run(load_window(s, len, e0), s, len, e0, is_signed, r) != SEG_OK) return fail();
+        size = readfirstlane64(r.run_end - e0);
+    }
+    const uint64_t pos = e0 + (uint64_t)k * size;
+    if (pos >= len) return fail();
+    const uint64_t wbase = (uint64_t)g << WINDOW_SHIFT;
+    if (g + 1 == n_win) {  // the stream's last window
+        ParsedRun r;
+        if (parse_run(load_window(s, len, pos), s, len, pos, is_signed, r) != SEG_OK) return fail();
+        if ((uint64_t)r.len < num_values - wbase) return fail();  // another run follows inside the window
+        const uint64_t desc = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes);
+        decode_single_run(wv, readfirstlane64(desc), wbase, readfirstlane64(r.base), readfirstlane64(r.aux));
+        return;
+    }
+    if (size < 2 + 64 || ((size - 2) & 63) != 0 || pos + size > len) return fail();
+    const uint32_t w = (uint32_t)((size - 2) >> 6);
+    const uint32_t code = code_from_width(w);
+    if (code > 31) return fail();
+    const uint64_t origin = stage_bytes(wv, pos, pos + size);  // size <= 4098: fits the slice
+    const uint32_t o = (uint32_t)(pos - origin);
+    // "01 code 1" + 0xFF: Direct, this width, length 512 (rle_v2.rs:135-146)
+    if (lds_bits32(wv.lds, o * 8, 16) != (((0x40u | (code << 1) | 1u) << 8) | 0xFFu)) return fail();
+    const bool zz = is_signed != 0;
+    const uint32_t bit_lane = (o + 2) * 8 + 2u * (uint32_t)wv.lane * w;
+    int64_t *wout = out + wbase;
+    if (w <= 32) direct_window<true, false>(wv, wout, w, zz, 0, bit_lane, 0, WINDOW);
+    else direct_window<true, true>(wv, wout, w, zz, 0, bit_lane, 0, WINDOW);
+}
+
+// What a speculative launch came to, where the host can see it: *flag into the `error` field of
+// the pinned totals, stamped last (the protocol of block_totals_scan_kernel).  The flag is left
+// zero for the next launch.
+__global__ void spec_publish_kernel(uint32_t *__restrict__ flag, ScanTotals *host_totals, uint32_t stamp) {
+    if (threadIdx.x || blockIdx.x) return;
+    volatile ScanTotals *h = host_totals;
+    h->error = *flag;
+    *flag = 0;
+    __threadfence_system();
+    h->pad = stamp;
+}
+
+hipError_t launch_rlev2_strided_values(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                       const uint64_t *entries, uint32_t n_seg, uint32_t n_win,
+                                       uint64_t num_values, int is_signed, int64_t *out, uint32_t *flag,
+                                       ScanTotals *host_totals, uint32_t stamp) {
+    if (n_win == 0 || n_seg == 0 || (((uintptr_t)out) & 15)) return hipErrorInvalidValue;
+    const uint32_t blocks = (n_win + VAL_WAVES - 1) / VAL_WAVES;
+    rlev2_strided_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, entries, n_seg, n_win,
+                                                                  num_values, is_signed, out, flag);
+    spec_publish_kernel<<<1, 64, 0, st>>>(flag, host_totals, stamp);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 

@@ -40,6 +40,8 @@ pub const ORCD_CHECK_UTF8: c_uint = 8;
 pub const ORCD_SCATTER_CARRY: c_uint = 16;
 pub const ORCD_ROW_ALIGNED: c_uint = 32;
 pub const ORCD_ENTRIES_HOST: c_uint = 64;
+pub const ORCD_PATH_GENERAL: c_int = 0;
+pub const ORCD_PATH_STRIDED: c_int = 1;
 
 // stream kinds (src/proto.rs:127-136) and column encodings (src/proto.rs:149-154)
 pub const ORCD_STREAM_PRESENT: c_int = 0;
@@ -115,6 +117,7 @@ extern "C" {
     pub fn orcd_ctx_release_cached(ctx: *mut orcd_ctx) -> c_int;
     pub fn orcd_ctx_last_elapsed_ms(ctx: *mut orcd_ctx) -> c_float;
     pub fn orcd_ctx_phase_ms(ctx: *mut orcd_ctx, phase: c_int) -> c_float;
+    pub fn orcd_ctx_last_path(ctx: *mut orcd_ctx) -> c_int;
     pub fn orcd_ctx_last_hip_error(ctx: *mut orcd_ctx) -> *const c_char;
     pub fn orcd_rlev2_decode(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_values: usize,
                              entry_points: *const u64, n_entries: usize, out: *mut i64,
