@@ -125,6 +125,29 @@ int orcd_rlev2_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t n
                       const uint64_t *entry_points, size_t n_entries, int64_t *out,
                       unsigned flags);
 
+/* orcd_rlev2_decode without any allocation.  No counterpart in the crate: this is for callers that
+ * cannot allocate device memory at the point of the call -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  `stream`, `entry_points` and `out` are DEVICE
+ * pointers (the ORCD_IN_DEVICE / ORCD_OUT_DEVICE / ORCD_ENTRIES_HOST flags are not consulted; only
+ * ORCD_SIGNED is), the results are those of orcd_rlev2_decode, and everything the kernels keep
+ * beside input and output lives in a static device array of the library (under 8 MiB, held by every
+ * GPU the library runs on until the process ends) instead of the context's growing buffers.  That
+ * sets limits, beyond which the call returns ORCD_INVALID_ARGUMENT without decoding:
+ *   num_values <= ORCD_NOALLOC_MAX_VALUES, n_entries <= ORCD_NOALLOC_MAX_ENTRIES, and the stream as a
+ *   whole (trailing runs included) holds at most ORCD_NOALLOC_MAX_VALUES values in at most
+ *   ORCD_NOALLOC_MAX_RUNS runs.
+ * A long stream without entry points is walked serially (the entry-point guesser of
+ * orcd_rlev2_decode allocates).  All calls on one GPU share the one array, whatever their context:
+ * calls that overlap in time on one GPU race and must be serialized by the caller. */
+enum {
+    ORCD_NOALLOC_MAX_VALUES = 16777216, /* 2^24 */
+    ORCD_NOALLOC_MAX_ENTRIES = 65536,
+    ORCD_NOALLOC_MAX_RUNS = 524288
+};
+int orcd_rlev2_decode_noalloc(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_values,
+                              const uint64_t *entry_points, size_t n_entries, int64_t *out,
+                              unsigned flags);
+
 /* Several RLE v2 streams that lie in one buffer -- the DATA streams of the integer columns of a
  * stripe, say -- decoded by one set of kernel launches instead of one set per stream (a call costs
  * about 50 microseconds whatever its size, which is what small columns are bounded by).  No

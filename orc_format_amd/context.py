@@ -274,6 +274,15 @@ class Context:
                                          (N.SIGNED if signed else 0) | N.IN_DEVICE | N.OUT_DEVICE)
         check(rc, self._h)
 
+    def rlev2_device_noalloc(self, stream_ptr, length, num_values, signed, out_ptr, entries_ptr=0,
+                             n_entries=0):
+        """orcd_rlev2_decode_noalloc: the same decode with every table in the library's static
+        device array; device pointers only, limits instead of growth (ORCD_INVALID_ARGUMENT)."""
+        rc = self._lib.orcd_rlev2_decode_noalloc(self._h, stream_ptr, length, num_values,
+                                                 entries_ptr or None, n_entries, out_ptr,
+                                                 N.SIGNED if signed else 0)
+        check(rc, self._h)
+
     def boolean_device(self, stream_ptr, length, num_bits, out_bytes_ptr=0, out_bitmap_ptr=0,
                        entries_ptr=0, n_entries=0, want_count=True):
         ones = C.c_uint64(0)

@@ -179,8 +179,59 @@ struct CopyThreads {
     }
 };
 
+// ---- device memory of orcd_rlev2_decode_noalloc ------------------------------------------------
+// That entry point may not allocate, so everything its kernels keep beside the caller's input and
+// output -- segment counts and offsets, workgroup totals, the run table, the per-window tables, the
+// flag of the speculative launch -- lives in this array, which every GPU the library runs on holds
+// from the moment the code object is loaded.  Its name is a host-side stand-in, not a device
+// address: the address on a device comes from hipGetSymbolAddress with that device current
+// (noalloc_scratch), and only that pointer is handed to kernels, memsets and copies.
+namespace {
+constexpr uint32_t NOALLOC_MAX_SEGMENTS = ORCD_NOALLOC_MAX_ENTRIES;
+constexpr uint64_t NOALLOC_MAX_VALUES = ORCD_NOALLOC_MAX_VALUES;   // values asked for, and values the stream holds
+constexpr uint64_t NOALLOC_MAX_RUNS = ORCD_NOALLOC_MAX_RUNS;       // runs the stream holds
+constexpr uint64_t NOALLOC_MAX_WINDOWS = (NOALLOC_MAX_VALUES >> WINDOW_SHIFT) + 2;
+constexpr size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
+constexpr size_t NA_SEG_COUNT = 0;
+constexpr size_t NA_SEG_OFF = NA_SEG_COUNT + up256(NOALLOC_MAX_SEGMENTS * sizeof(SegCount));
+constexpr size_t NA_BLK = NA_SEG_OFF + up256(NOALLOC_MAX_SEGMENTS * sizeof(SegOffset));
+constexpr size_t NA_BOFF = NA_BLK + up256(NOALLOC_MAX_SEGMENTS / SEG_BLOCK * sizeof(BlockTotals));
+constexpr size_t NA_TOTALS = NA_BOFF + up256(NOALLOC_MAX_SEGMENTS / SEG_BLOCK * sizeof(BlockOffset));
+constexpr size_t NA_FLAG = NA_TOTALS + up256(sizeof(ScanTotals));
+constexpr size_t NA_RUNS = NA_FLAG + 256;
+constexpr size_t NA_GROUPS = NA_RUNS + up256((NOALLOC_MAX_RUNS + 1) * sizeof(uint64_t));
+constexpr size_t NA_GROUP_RUNS = NA_GROUPS + up256(NOALLOC_MAX_WINDOWS * sizeof(uint32_t));
+constexpr size_t NA_BYTES = NA_GROUP_RUNS + up256(NOALLOC_MAX_WINDOWS * sizeof(RunEntry));
+static_assert(NA_BYTES < (8u << 20), "the static scratch array is meant to stay modest");
+constexpr int NOALLOC_MAX_DEVICES = 64;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[NA_BYTES];
+
+namespace {
+std::mutex g_scratch_lock;
+unsigned char *g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};  // per device: each GPU holds its own copy
+
+// Address of `scratch` on the current device (which must be `device`); looked up once per device.
+hipError_t noalloc_scratch(int device, unsigned char **ptr) {
+    *ptr = nullptr;
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> g(g_scratch_lock);
+    if (!g_scratch_ptr[device]) {
+        unsigned char *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = p;
+    }
+    *ptr = g_scratch_ptr[device];
+    return hipSuccess;
+}
+}  // namespace
+
 struct orcd_ctx {
     int device = 0;
+    unsigned char *scratch_dev = nullptr;  // this device's copy of `scratch` (see noalloc_scratch)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[N_EVENTS] = {};
@@ -572,8 +623,10 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
 constexpr size_t SPEC_MIN_VALUES = 8 * WINDOW;
 constexpr uint32_t SPEC_BACKOFF = 16;
 
+// flag_word (nullable): the device word to use instead of the context's own, zero on entry.
 int try_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
-                const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done) {
+                const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done,
+                uint32_t *flag_word = nullptr) {
     *done = false;
     if (num_values < SPEC_MIN_VALUES || (((uintptr_t)d_out) & 15) || n_entries > 0xFFFFFFFFull) return ORCD_OK;
     const uint64_t n_win = (num_values + WINDOW - 1) >> WINDOW_SHIFT;
@@ -583,12 +636,14 @@ int try_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
         c->spec_skip--;
         return ORCD_OK;
     }
-    // the flag word is zero between launches: the publishing kernel leaves it so
-    void *flag;
-    ORCD_TRY(ensure(c, SLOT_SPEC_FLAG, 256, &flag));
-    if (!c->spec_flag_clean) {
-        HIP_TRY(c, hipMemsetAsync(flag, 0, 256, c->stream));
-        c->spec_flag_clean = true;
+    // the context's flag word is zero between launches: the publishing kernel leaves it so
+    void *flag = flag_word;
+    if (!flag) {
+        ORCD_TRY(ensure(c, SLOT_SPEC_FLAG, 256, &flag));
+        if (!c->spec_flag_clean) {
+            HIP_TRY(c, hipMemsetAsync(flag, 0, 256, c->stream));
+            c->spec_flag_clean = true;
+        }
     }
     const uint32_t stamp = next_stamp(c);
     HIP_TRY(c, launch_rlev2_strided_values(c->stream, d_stream, len, n_entries ? d_entries : nullptr,
@@ -749,6 +804,7 @@ int orcd_ctx_create(int device_id, orcd_ctx **out) try {
     for (int i = 0; ok && i < N_EVENTS; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->h_totals, sizeof(ScanTotals), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
     if (ok) memset(c->h_totals, 0, sizeof(ScanTotals));
+    ok = ok && noalloc_scratch(device_id, &c->scratch_dev) == hipSuccess;  // device_id is current here
     ok = ok && hipHostMalloc((void **)&c->h_scalars, 8 * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
     if (!ok) {
         orcd_ctx_destroy(c);
@@ -857,6 +913,79 @@ int orcd_rlev2_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num
     ORCD_TRY(rlev2_device(c, (const uint8_t *)d_stream, len, num_values, (const uint64_t *)d_entries,
                           n_entries, (flags & ORCD_SIGNED) ? 1 : 0, d_out));
     if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, num_values * sizeof(int64_t)));
+    return ORCD_OK;
+} ORCD_CATCH
+
+// orcd_rlev2_decode for callers that cannot allocate: device pointers only, every table in the
+// library's static device array, limits instead of growth.
+int orcd_rlev2_decode_noalloc(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_values,
+                              const uint64_t *entry_points, size_t n_entries, int64_t *out,
+                              unsigned flags) try {
+    if (!c || (len && !stream) || (num_values && !out) || (n_entries && !entry_points))
+        return ORCD_INVALID_ARGUMENT;
+    if (num_values == 0) return ORCD_OK;
+    if (num_values > NOALLOC_MAX_VALUES || n_entries > NOALLOC_MAX_SEGMENTS || len > RUN_PAYLOAD_MASK)
+        return ORCD_INVALID_ARGUMENT;  // beyond what the static tables hold
+    DeviceGuard g(c->device);
+    unsigned char *base = c->scratch_dev;
+    if (!base) {  // the context was created before the symbol could be resolved: once more, this device current
+        HIP_TRY(c, noalloc_scratch(c->device, &base));
+        c->scratch_dev = base;
+    }
+    const int is_signed = (flags & ORCD_SIGNED) ? 1 : 0;
+    reset_events(c);
+    mark(c, 0);
+    c->last_path = ORCD_PATH_GENERAL;
+    // the array keeps what the last call left: the one word that must start at zero is cleared
+    uint32_t *flag = (uint32_t *)(base + NA_FLAG);
+    HIP_TRY(c, hipMemsetAsync(flag, 0, 256, c->stream));
+    bool done = false;
+    ORCD_TRY(try_strided(c, stream, len, num_values, entry_points, n_entries, is_signed, out, &done, flag));
+    if (done) {
+        c->last_path = ORCD_PATH_STRIDED;
+        return ORCD_OK;
+    }
+    const uint32_t n_seg = segments_for(n_entries);
+    const uint64_t *entries = n_entries ? entry_points : nullptr;
+    const uint32_t n_blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
+    SegTable t;
+    t.seg_count = (SegCount *)(base + NA_SEG_COUNT);
+    t.seg_local = (SegOffset *)(base + NA_SEG_OFF);
+    t.blk = (BlockTotals *)(base + NA_BLK);
+    t.boff = (BlockOffset *)(base + NA_BOFF);
+    t.totals = (ScanTotals *)(base + NA_TOTALS);
+    t.host_totals = c->h_totals;
+    t.host_stamp = next_stamp(c);
+    if (n_seg <= COOP_MAX_SEGMENTS)
+        HIP_TRY(c, launch_rlev2_coop_count(c->stream, stream, len, entries, nullptr, n_seg, is_signed, t, nullptr, 0));
+    else
+        HIP_TRY(c, launch_rlev2_count(c->stream, stream, len, entries, nullptr, n_seg, is_signed, t, nullptr, 0));
+    HIP_TRY(c, launch_block_totals_scan(c->stream, t, n_blocks, num_values));
+    ORCD_TRY(wait_totals_stamp(c, t.host_stamp, t.totals));
+    mark(c, 1);
+    const ScanTotals totals = *c->h_totals;
+    if (totals.error) return (int)totals.error;
+    const uint64_t n_slots = ((totals.total_vals + WINDOW - 1) >> WINDOW_SHIFT) + 1;
+    if (totals.total_runs > NOALLOC_MAX_RUNS || n_slots > NOALLOC_MAX_WINDOWS)
+        return ORCD_INVALID_ARGUMENT;  // the stream holds more than the static tables do
+    uint64_t *runs = (uint64_t *)(base + NA_RUNS);
+    uint32_t *groups = (uint32_t *)(base + NA_GROUPS);
+    RunEntry *group_runs = (RunEntry *)(base + NA_GROUP_RUNS);
+    HIP_TRY(c, launch_rlev2_emit(c->stream, stream, len, entries, nullptr, n_seg, is_signed, t, runs, groups,
+                                 group_runs, (uint32_t)n_slots, false, 0));
+    mark(c, 2);
+    Rlev2Table tab;
+    tab.stream = stream;
+    tab.len = len;
+    tab.runs = runs;
+    tab.group_first = groups;
+    tab.group_run = group_runs;
+    tab.n_groups = (uint32_t)((std::min<uint64_t>(num_values, totals.total_vals) + WINDOW - 1) >> WINDOW_SHIFT);
+    tab.n_runs = (uint32_t)totals.total_runs;
+    tab.num_values = num_values;
+    tab.is_signed = is_signed;
+    HIP_TRY(c, launch_rlev2_values(c->stream, tab, out));
+    mark(c, 3);
     return ORCD_OK;
 } ORCD_CATCH
 

@@ -40,6 +40,9 @@ pub const ORCD_CHECK_UTF8: c_uint = 8;
 pub const ORCD_SCATTER_CARRY: c_uint = 16;
 pub const ORCD_ROW_ALIGNED: c_uint = 32;
 pub const ORCD_ENTRIES_HOST: c_uint = 64;
+pub const ORCD_NOALLOC_MAX_VALUES: usize = 16777216;
+pub const ORCD_NOALLOC_MAX_ENTRIES: usize = 65536;
+pub const ORCD_NOALLOC_MAX_RUNS: usize = 524288;
 pub const ORCD_PATH_GENERAL: c_int = 0;
 pub const ORCD_PATH_STRIDED: c_int = 1;
 
@@ -122,6 +125,9 @@ extern "C" {
     pub fn orcd_rlev2_decode(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_values: usize,
                              entry_points: *const u64, n_entries: usize, out: *mut i64,
                              flags: c_uint) -> c_int;
+    pub fn orcd_rlev2_decode_noalloc(ctx: *mut orcd_ctx, stream: *const u8, len: usize,
+                                     num_values: usize, entry_points: *const u64, n_entries: usize,
+                                     out: *mut i64, flags: c_uint) -> c_int;
     pub fn orcd_rlev2_runs(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_values: usize,
                            entry_points: *const u64, n_entries: usize, runs: *mut orcd_run,
                            max_runs: usize, n_runs: *mut usize, flags: c_uint) -> c_int;
