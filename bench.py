@@ -50,6 +50,27 @@ DEFAULT_ROWS = {"strings_w6": 250_000_000, "boolean_mix": 4_000_000_000, "mixed_
                 "mixed_short_runs_sparse": 500_000_000}
 
 
+EXTRA_WORKLOADS = ["delta_w10", "delta_w16", "mixed_short_runs", "boolean_mix", "strings_w6"]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: starts N fresh rank processes (this
+    process has not touched the GPU and never does), one per GPU, that meet over RCCL on
+    127.0.0.1, and exits with the worst of their exit codes.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    sys.exit(max(abs(c) for c in codes))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,11 +80,16 @@ def main():
                     help="values per GPU per step (default 1e9; 2.5e8 strings for strings_w6)")
     ap.add_argument("--workload", default="direct_w17", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the `workloads` object (the other configurations, shorter runs)")
     ap.add_argument("--end-to-end", action="store_true",
                     help="also measure host -> device -> decode -> host (reported separately)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target duration of the CPU baseline sample")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)   # before anything here touches a GPU
 
     import numpy as np
     import torch
@@ -73,8 +99,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run "
-                  "--nproc-per-node %d)" % (args.gpus, world, args.gpus), file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     # ORCD_BENCH_REHEARSAL=1: the ranks share GPU 0 and meet over gloo, to exercise the multi-rank
     # code on a one-GPU box; its numbers mean nothing and the result line says so
@@ -92,16 +117,51 @@ def main():
     global REDUCE_DEVICE
     REDUCE_DEVICE = "cpu" if rehearsal else "cuda"
 
+    explicit_rows = args.rows
+    result = run_workload(args, args.workload, rank, world, local_rank, dist, torch, np)
+    # The other configurations of BASELINE.json beside the headline, as shorter runs of the same
+    # code: value, roofline of the dominant kernel and CPU baseline each (one GPU, default sizes).
+    if (args.workload == "direct_w17" and world == 1 and explicit_rows is None
+            and not args.headline_only):
+        result["workloads"] = {}
+        for wl in EXTRA_WORKLOADS:
+            sub = argparse.Namespace(**vars(args))
+            sub.rows, sub.steps, sub.warmup = None, min(args.steps, 10), min(args.warmup, 2)
+            sub.cpu_seconds, sub.end_to_end = min(args.cpu_seconds, 4.0), False
+            torch.cuda.empty_cache()
+            r = run_workload(sub, wl, rank, world, local_rank, dist, torch, np)
+            keep = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "roofline",
+                                      "phases_ms", "decoded_frac_of_hbm_peak", "cpu_baseline",
+                                      "zero_copy_variant") if k in r}
+            keep["workload"] = r["config"]["workload"]
+            result["workloads"][wl] = keep
+    if rank == 0:
+        if rehearsal:
+            result["rehearsal"] = "ranks shared one GPU over gloo: not a measurement"
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_workload(args, workload, rank, world, local_rank, dist, torch, np):
+    gen_name, gen_kw, signed, desc = WORKLOADS[workload]
+    args = argparse.Namespace(**vars(args))
+    args.workload = workload
+    if args.rows is None:
+        args.rows = DEFAULT_ROWS.get(workload, 1_000_000_000)
+    if workload == "strings_w6":
+        return bench_strings(args, rank, world, local_rank, dist, desc, torch, np)
+    if workload == "boolean_mix":
+        return bench_boolean(args, rank, world, local_rank, dist, desc, torch, np)
+    return bench_rlev2(args, rank, world, local_rank, dist, torch, np)
+
+
+def bench_rlev2(args, rank, world, local_rank, dist, torch, np):
     from bench_util import synth
     from orc_format_amd import Context
 
     gen_name, gen_kw, signed, desc = WORKLOADS[args.workload]
-    if args.rows is None:
-        args.rows = DEFAULT_ROWS.get(args.workload, 1_000_000_000)
-    if args.workload == "strings_w6":
-        return bench_strings(args, rank, world, local_rank, dist, desc, torch, np)
-    if args.workload == "boolean_mix":
-        return bench_boolean(args, rank, world, local_rank, dist, desc, torch, np)
     # every rank decodes a different stripe set (seed offset by rank)
     seed = {"direct_w17": 42, "delta_monotonic": 43, "mixed_short_runs": 44}[gen_name] + 1000 * rank
     if gen_name == "mixed_short_runs":
@@ -199,13 +259,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, stream, rows, stream_bytes, signed, expect, np, cuts)
-    if rank == 0:
-        if os.environ.get("ORCD_BENCH_REHEARSAL") == "1":
-            result["rehearsal"] = "ranks shared one GPU over gloo: not a measurement"
-        print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return result
 
 
 def attach_traffic(result, workload, kernel):
@@ -344,13 +398,7 @@ def bench_strings(args, rank, world, local_rank, dist, desc, torch, np):
             "value": round((nbytes + 8 * (n_s + 1)) / dt / 1e9, 4), "unit": "GB/s", "cores": 1,
             "kind": "port", "sample": "first %d strings (%.1f MB of DATA) of the same column, single "
                                       "thread, %.1f s" % (n_s, nbytes / 1e6, dt)}
-    if rank == 0:
-        if os.environ.get("ORCD_BENCH_REHEARSAL") == "1":
-            result["rehearsal"] = "ranks shared one GPU over gloo: not a measurement"
-        print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return result
 
 
 def bench_boolean(args, rank, world, local_rank, dist, desc, torch, np):
@@ -440,13 +488,7 @@ def bench_boolean(args, rank, world, local_rank, dist, desc, torch, np):
         result["cpu_baseline"] = {
             "value": round(n_s / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
             "sample": "first %d values of the same stream, single thread, %.1f s" % (n_s, dt)}
-    if rank == 0:
-        if os.environ.get("ORCD_BENCH_REHEARSAL") == "1":
-            result["rehearsal"] = "ranks shared one GPU over gloo: not a measurement"
-        print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return result
 
 
 def end_to_end(args, ctx, stream, entries, expect, rows, signed, torch):

@@ -160,7 +160,8 @@ int orcd_rlev2_decode_noalloc(orcd_ctx *ctx, const uint8_t *stream, size_t len, 
  * anything else is ORCD_INVALID_ARGUMENT.  The values of slice i are written to out + (sum of num_values of the slices before i).
  * A slice that does not hold exactly its num_values values, or does not parse, yields
  * ORCD_OUT_OF_SPEC with *bad_slice (nullable) set to a slice at or before the first bad one;
- * decode the slices one by one to pin it down. */
+ * decode the slices one by one to pin it down.  The last slice alone may hold more than its
+ * num_values: what follows them is ignored, as at the end of a stream given to orcd_rlev2_decode. */
 typedef struct {
     uint64_t offset, length, num_values;
     const uint64_t *entry_points;

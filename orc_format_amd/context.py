@@ -34,7 +34,8 @@ def _column_dict(cd):
     out = {"type_kind": cd.type_kind, "num_values": cd.num_values,
            "validity": arr(cd.validity, cd.num_rows, np.uint8).astype(bool)}
     if cd.values:
-        dtype = {(5, 4): np.float32, (6, 8): np.float64}.get(
+        # FLOAT / DOUBLE by type; BYTE (tinyint) is signed; BOOLEAN stays one byte 0 / 1
+        dtype = {(5, 4): np.float32, (6, 8): np.float64, (1, 1): np.int8}.get(
             (cd.type_kind, cd.value_size), {8: np.int64, 1: np.uint8}.get(cd.value_size))
         out["values"] = arr(cd.values, cd.num_slots, dtype)
     if cd.offsets:

@@ -1709,6 +1709,11 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
     case T_SHORT: case T_INT: case T_LONG: case T_DATE: {  // deserialize_int_array, deserialize.rs:48-82
         value_size = 8;
         if (ints_done) break;
+        // ColumnEncoding DIRECT is RLE v1 (Hive 0.11 files), which is not decoded here: its bytes
+        // must not be read as RLE v2
+        int enc = 0;
+        ORCD_TRY(orcd_column_encoding(col, &enc, nullptr));
+        if (enc != ORCD_ENC_DIRECT_V2) return ORCD_UNSUPPORTED;
         ORCD_TRY(dev_alloc(c, n_values * 8, &p.values));
         ORCD_TRY(cs.get(ORCD_STREAM_DATA, &sb, &sl, &ent, &n_ent, n_values != 0));
         ORCD_TRY(orcd_rlev2_decode(c, sb, sl, n_values, ent, n_ent, (int64_t *)p.values, ORCD_SIGNED | io));
@@ -1924,6 +1929,11 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
         sb.hi = std::max(sb.hi, off + n);
     }
     if (sb.lo > sb.hi) sb.lo = sb.hi = 0;
+    if (si.offset + sb.lo < si.offset) return ORCD_OUT_OF_SPEC;  // offsets a file cannot have
+    {   // the region must lie inside the file before memory of its size is asked for
+        uint8_t probe;
+        if (sb.hi > sb.lo) ORCD_TRY(orcd_file_read_at(file, si.offset + sb.lo + (sb.hi - sb.lo - 1), 1, &probe));
+    }
     ORCD_TRY(dev_alloc(c, sb.hi - sb.lo, &stripe_mem.tmp));
     sb.d_base = (const uint8_t *)stripe_mem.tmp;
     const HostSource region = {file, si.offset + sb.lo, nullptr};
@@ -1979,6 +1989,9 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
         uint64_t total = 0;
         for (size_t i = 0; i < n_columns; i++) {
             if (!is_int_kind((*jobs[i]).type_kind) || (*jobs[i]).n_values == 0) continue;
+            int enc = 0;
+            if (orcd_column_encoding((*jobs[i]).col, &enc, nullptr) != ORCD_OK || enc != ORCD_ENC_DIRECT_V2)
+                continue;  // RLE v1 or unknown: reported per column below
             const ColumnStreams cs{file, (*jobs[i]).col, &sb};
             const uint8_t *b;
             size_t l, n_ent;

@@ -23,6 +23,14 @@ namespace {
 
 constexpr uint64_t DEFAULT_FOOTER_SIZE = 16 * 1024;  // src/read/mod.rs:22
 
+// Every length and offset in a file is a varint of up to 64 bits that a crafted file may set to
+// anything: sums of them are formed with these, and an overflow is a malformed file.
+inline bool add_ok(uint64_t a, uint64_t b, uint64_t &out) { return !__builtin_add_overflow(a, b, &out); }
+inline bool add3_ok(uint64_t a, uint64_t b, uint64_t c, uint64_t &out) {
+    uint64_t t;
+    return add_ok(a, b, t) && add_ok(t, c, out);
+}
+
 // ---- protobuf wire format --------------------------------------------------------------------
 
 struct Cursor {
@@ -183,12 +191,14 @@ int parse_tail(orcd_file *f) {
     }
     if (!has_footer_length) return ORCD_OUT_OF_SPEC;  // src/read/mod.rs:73
     if (f->compression != 0) return ORCD_UNSUPPORTED;  // only CompressionKind::None is decoded
-    const uint64_t need = 1 + ps_len + footer_length + metadata_length;
-    if (need > s.len) return ORCD_OUT_OF_SPEC;
+    uint64_t need;
+    if (!add3_ok(1 + ps_len, footer_length, metadata_length, need) || need > s.len) return ORCD_OUT_OF_SPEC;
     if (need > tail_len) {  // the crate panics here; re-read the tail at its exact size
         tail_len = need;
         if (!s.read_at(s.len - tail_len, tail_len, tail)) return ORCD_OUT_OF_SPEC;
     }
+    // (need <= tail_len now, so the footer lies inside the buffer)
+    if (footer_length > tail_len - 1 - ps_len) return ORCD_OUT_OF_SPEC;
     const uint8_t *footer_end = tail.data() + tail_len - 1 - ps_len;
     Cursor c{footer_end - footer_length, footer_end};
     uint32_t field, wire;
@@ -252,7 +262,7 @@ int parse_stripe_footer(const std::vector<uint8_t> &buf, orcd_stripe_footer *out
             }
             if (!sub.ok) return ORCD_INVALID_PROTO;
             si.offset = offset;  // streams are laid out back to back (src/read/mod.rs:127-138)
-            offset += si.length;
+            if (!add_ok(offset, si.length, offset)) return ORCD_OUT_OF_SPEC;
             out->streams.push_back(si);
         } else if (field == 2 && wire == 2) {  // ColumnEncoding
             Encoding e;
@@ -324,7 +334,9 @@ int load_entry_points(orcd_file *file, orcd_column *col) {
     }
     std::vector<uint8_t> buf;
     const orcd_stripe_info &si = file->stripes[col->stripe];
-    if (!file->src.read_at(si.offset + index->offset, index->length, buf)) return ORCD_OUT_OF_SPEC;
+    uint64_t index_at;
+    if (!add_ok(si.offset, index->offset, index_at) || !file->src.read_at(index_at, index->length, buf))
+        return ORCD_OUT_OF_SPEC;
     Cursor c{buf.data(), buf.data() + buf.size()};
     uint32_t field, wire;
     uint64_t v;
@@ -422,7 +434,9 @@ int orcd_read_stripe_footer(orcd_file *f, size_t stripe, orcd_stripe_footer **ou
     if (stripe >= f->stripes.size()) return ORCD_INVALID_ARGUMENT;
     const orcd_stripe_info &si = f->stripes[stripe];
     std::vector<uint8_t> buf;
-    if (!f->src.read_at(si.offset + si.index_length + si.data_length, si.footer_length, buf))
+    uint64_t footer_at;
+    if (!add3_ok(si.offset, si.index_length, si.data_length, footer_at) ||
+        !f->src.read_at(footer_at, si.footer_length, buf))
         return ORCD_OUT_OF_SPEC;
     orcd_stripe_footer *ft = new orcd_stripe_footer();
     ft->stripe = stripe;
@@ -460,11 +474,13 @@ int orcd_read_stripe_column(orcd_file *f, size_t stripe, const orcd_stripe_foote
             found = true;
             start = s.offset;
         }
-        length += s.length;
+        if (!add_ok(length, s.length, length)) return ORCD_OUT_OF_SPEC;
     }
     if (!found) return ORCD_INVALID_COLUMN;
+    uint64_t region_at;
+    if (!add_ok(f->stripes[stripe].offset, start, region_at)) return ORCD_OUT_OF_SPEC;
     orcd_column *col = new orcd_column();
-    if (!f->src.read_at(f->stripes[stripe].offset + start, length, col->data)) {
+    if (!f->src.read_at(region_at, length, col->data)) {
         delete col;
         return ORCD_OUT_OF_SPEC;
     }
@@ -508,7 +524,7 @@ int orcd_column_region(const orcd_column *col, uint64_t *offset, uint64_t *len) 
             found = true;
             start = s.offset;
         }
-        length += s.length;
+        if (!add_ok(length, s.length, length)) return ORCD_OUT_OF_SPEC;
     }
     if (!found) return ORCD_INVALID_COLUMN;
     *offset = start;
@@ -527,11 +543,12 @@ int orcd_column_stream_range(const orcd_column *col, int kind, uint64_t *offset,
     for (const auto &s : col->footer->streams) {
         if (s.column != col->column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
         if ((int)s.kind == kind) {
-            *offset = region + start;
+            if (start > region_len || s.length > region_len - start) return ORCD_OUT_OF_SPEC;
+            *offset = region + start;  // inside the region, whose end was formed without overflow
             *len = s.length;
             return ORCD_OK;
         }
-        start += s.length;
+        if (!add_ok(start, s.length, start)) return ORCD_OUT_OF_SPEC;
     }
     return ORCD_INVALID_KIND;
 } ORCD_CATCH
@@ -548,12 +565,12 @@ int orcd_column_get_stream(const orcd_column *col, int kind, const uint8_t **byt
     for (const auto &s : col->footer->streams) {
         if (s.column != col->column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
         if ((int)s.kind == kind) {
-            if (start + s.length > col->data.size()) return ORCD_OUT_OF_SPEC;
+            if (start > col->data.size() || s.length > col->data.size() - start) return ORCD_OUT_OF_SPEC;
             *bytes = col->data.data() + start;
             *len = (size_t)s.length;
             return ORCD_OK;
         }
-        start += s.length;
+        if (!add_ok(start, s.length, start)) return ORCD_OUT_OF_SPEC;
     }
     return ORCD_INVALID_KIND;
 } ORCD_CATCH

@@ -66,8 +66,11 @@ def decode_file_shard(ctx, metadata, rank, world_size, columns=None, row_aligned
     needed to assemble the table (reference: the stripe loop of tests/it/main.rs:8-24, which this
     spreads over ranks).
 
-    extra_contexts: more contexts on the same GPU; the rank's stripes are then dealt to one host
-    thread per context, so that one stripe's read and copy overlap another's decode."""
+    extra_contexts: more contexts on the same GPU.  A context belongs to one thread at a time
+    (it has no lock: its buffers, pinned words and stamps are per call), so every context gets one
+    host thread of its own, which decodes that context's share of the stripes -- every
+    len(contexts)-th of the rank's -- one after the other; one stripe's read and copy then overlap
+    another's decode on a different context."""
     from . import read
     if columns is None:
         columns = list(range(1, len(metadata.types)))
@@ -75,15 +78,30 @@ def decode_file_shard(ctx, metadata, rank, world_size, columns=None, row_aligned
     mine = stripes_of_rank(metadata, rank, world_size)
     contexts = [ctx] + list(extra_contexts)
 
-    def one(job):
-        k, stripe = job
+    def one(context, stripe):
         footer = read.read_stripe_footer(metadata, stripe)
         return (stripe, first_rows[stripe],
-                contexts[k].decode_stripe(metadata, stripe, footer, columns, check_utf8=check_utf8,
-                                          row_aligned=row_aligned))
-    jobs = [(i % len(contexts), stripe) for i, stripe in enumerate(mine)]
+                context.decode_stripe(metadata, stripe, footer, columns, check_utf8=check_utf8,
+                                      row_aligned=row_aligned))
     if len(contexts) == 1:
-        return [one(j) for j in jobs]
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(len(contexts)) as pool:
-        return list(pool.map(one, jobs))
+        return [one(ctx, stripe) for stripe in mine]
+    import threading
+    results = [None] * len(mine)
+    errors = []
+
+    def drain(k):   # the only thread that ever enters contexts[k]
+        try:
+            for i in range(k, len(mine), len(contexts)):
+                if errors:
+                    return
+                results[i] = one(contexts[k], mine[i])
+        except BaseException as e:  # handed to the caller's thread below
+            errors.append(e)
+    threads = [threading.Thread(target=drain, args=(k,)) for k in range(len(contexts))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results

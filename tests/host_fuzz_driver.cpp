@@ -78,7 +78,127 @@ static int walk(const std::vector<uint8_t> &image) {
     return ORCD_OK;
 }
 
+// ---- hand-made images whose lengths are chosen so that their sums wrap around 64 bits --------
+static void put_varint(std::vector<uint8_t> &b, uint64_t v) {
+    while (v >= 0x80) {
+        b.push_back((uint8_t)(v | 0x80));
+        v >>= 7;
+    }
+    b.push_back((uint8_t)v);
+}
+static void put_u(std::vector<uint8_t> &b, uint32_t field, uint64_t v) {
+    put_varint(b, (uint64_t)field << 3);
+    put_varint(b, v);
+}
+static void put_msg(std::vector<uint8_t> &b, uint32_t field, const std::vector<uint8_t> &m) {
+    put_varint(b, ((uint64_t)field << 3) | 2);
+    put_varint(b, m.size());
+    b.insert(b.end(), m.begin(), m.end());
+}
+
+struct Crafted {
+    uint64_t stripe_offset = 0, index_length = 0, data_length = 24;
+    uint64_t stream_a = 16, stream_b = 8;   // DATA and LENGTH of column 1
+    uint64_t extra_metadata_length = 0;     // PostScript.metadataLength beyond what is there
+    uint64_t footer_length_override = 0;
+};
+
+static std::vector<uint8_t> craft(const Crafted &c) {
+    std::vector<uint8_t> image(24, 0x5a);   // the stripe's data area
+    std::vector<uint8_t> sf, st;
+    put_u(st, 1, 1); put_u(st, 2, 1); put_u(st, 3, c.stream_a);
+    put_msg(sf, 1, st);
+    st.clear();
+    put_u(st, 1, 2); put_u(st, 2, 1); put_u(st, 3, c.stream_b);
+    put_msg(sf, 1, st);
+    for (int k = 0; k < 2; k++) {
+        std::vector<uint8_t> enc;
+        put_u(enc, 1, 2);
+        put_msg(sf, 2, enc);
+    }
+    image.insert(image.end(), sf.begin(), sf.end());
+    std::vector<uint8_t> footer, si, ty;
+    put_u(si, 1, c.stripe_offset); put_u(si, 2, c.index_length); put_u(si, 3, c.data_length);
+    put_u(si, 4, sf.size()); put_u(si, 5, 5);
+    put_msg(footer, 3, si);
+    put_u(ty, 1, 12); put_u(ty, 2, 1);
+    put_msg(footer, 4, ty);
+    ty.clear();
+    put_u(ty, 1, 7);
+    put_msg(footer, 4, ty);
+    put_u(footer, 6, 5);
+    image.insert(image.end(), footer.begin(), footer.end());
+    std::vector<uint8_t> ps;
+    put_u(ps, 1, c.footer_length_override ? c.footer_length_override : footer.size());
+    put_u(ps, 2, 0);
+    put_u(ps, 5, c.extra_metadata_length);
+    image.insert(image.end(), ps.begin(), ps.end());
+    image.push_back((uint8_t)ps.size());
+    return image;
+}
+
+// 0 when every crafted image is handled (opened or refused) the way it should be
+static int crafted_images() {
+    Crafted ok;
+    if (walk(craft(ok)) != ORCD_OK) return 10;            // the builder itself makes a readable file
+    {   // footer_length + metadata_length wraps: the footer would start before the tail buffer
+        Crafted c;
+        c.footer_length_override = 1000;
+        c.extra_metadata_length = 0ull - 500;
+        if (walk(craft(c)) == ORCD_OK) return 11;
+        std::vector<uint8_t> big = craft(c);
+        big.insert(big.begin(), 600, 0);
+        if (walk(big) == ORCD_OK) return 12;
+    }
+    {   // the lengths of a column's streams wrap: the column buffer would be 8 bytes, the second
+        // stream "2^64 - 8 bytes at offset 16" of it
+        Crafted c;
+        c.stream_b = 0ull - 8;
+        std::vector<uint8_t> image = craft(c);
+        orcd_file *f = nullptr;
+        if (orcd_file_open_memory(image.data(), image.size(), &f) != ORCD_OK) return 13;
+        orcd_stripe_footer *ft = nullptr;
+        if (orcd_read_stripe_footer(f, 0, &ft) == ORCD_OK) {   // (refusing the footer is fine too)
+            orcd_column *col = nullptr;
+            if (orcd_read_stripe_column(f, 0, ft, 1, &col) == ORCD_OK) {
+                const uint8_t *bytes;
+                size_t len;
+                if (orcd_column_get_stream(col, 2, &bytes, &len) == ORCD_OK) return 14;
+                orcd_column_free(col);
+            }
+            orcd_column *bare = nullptr;
+            if (orcd_stripe_column_open(f, 0, ft, 1, &bare) == ORCD_OK) {
+                uint64_t off, n;
+                if (orcd_column_region(bare, &off, &n) == ORCD_OK) return 15;
+                if (orcd_column_stream_range(bare, 2, &off, &n) == ORCD_OK) return 16;
+                orcd_column_free(bare);
+            }
+            orcd_stripe_footer_free(ft);
+        }
+        orcd_file_close(f);
+        walk(image);
+    }
+    {   // offset + index_length + data_length of a stripe wraps to a small number
+        Crafted c;
+        c.stripe_offset = 0ull - 10;
+        c.index_length = 5;
+        c.data_length = 29;
+        std::vector<uint8_t> image = craft(c);
+        orcd_file *f = nullptr;
+        if (orcd_file_open_memory(image.data(), image.size(), &f) != ORCD_OK) return 17;
+        orcd_stripe_footer *ft = nullptr;
+        if (orcd_read_stripe_footer(f, 0, &ft) == ORCD_OK) return 18;
+        orcd_file_close(f);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    const int crafted = crafted_images();
+    if (crafted) {
+        printf("crafted image case %d\n", crafted);
+        return crafted;
+    }
     int opened = 0, refused = 0;
     for (int a = 1; a < argc; a++) {
         FILE *fp = fopen(argv[a], "rb");

@@ -87,3 +87,56 @@ def test_two_ranks_gloo(golden_dir, tmp_path):
         merged.update(results[r][1])
     got = np.concatenate([merged[s] for s in range(n_stripes)])
     assert (got == expect).all()
+
+
+class _ExclusiveContext:
+    """Stands in for a decode context: records the stripes it was given and fails if a second
+    thread enters it while a call is in progress (a real context has no lock)."""
+
+    def __init__(self, delays):
+        import threading
+        self.lock = threading.Lock()
+        self.delays = delays
+        self.seen = []
+        self.threads = set()
+
+    def decode_stripe(self, metadata, stripe, footer, columns, check_utf8=True, row_aligned=False):
+        import threading
+        import time
+        assert self.lock.acquire(blocking=False), "context entered by two threads at once"
+        try:
+            self.threads.add(threading.get_ident())
+            time.sleep(self.delays[stripe % len(self.delays)])
+            self.seen.append(stripe)
+            return [{"stripe": stripe, "columns": list(columns)}]
+        finally:
+            self.lock.release()
+
+
+def test_decode_file_shard_keeps_a_context_on_one_thread(golden_dir):
+    """Stripes of uneven duration on two and three contexts: every context is entered by one thread
+    only, never re-entered, and the results come back in the order of the rank's stripes."""
+    from orc_format_amd import read
+    md = read.read_metadata(os.path.join(golden_dir, "mixed_speed.orc"))
+    n = len(md.stripes)
+    assert n >= 4
+    delays = [0.05, 0.001, 0.02, 0.001, 0.03]
+    for n_ctx in (2, 3):
+        ctxs = [_ExclusiveContext(delays) for _ in range(n_ctx)]
+        for _ in range(3):   # several passes: more jobs than one file's stripes
+            for c in ctxs:
+                c.threads.clear()
+            out = shard.decode_file_shard(ctxs[0], md, 0, 1, columns=[1], extra_contexts=ctxs[1:])
+            assert all(len(c.threads) == 1 for c in ctxs)   # one thread per context
+            assert [o[0] for o in out] == list(range(n))
+            assert [o[1] for o in out] == shard.row_offsets([s.number_of_rows for s in md.stripes])
+            assert all(o[2][0]["stripe"] == o[0] for o in out)
+        for k, c in enumerate(ctxs):
+            assert sorted(set(c.seen)) == list(range(k, n, n_ctx))
+
+    class Failing(_ExclusiveContext):
+        def decode_stripe(self, *a, **kw):
+            raise RuntimeError("boom")
+    with pytest.raises(RuntimeError):
+        shard.decode_file_shard(_ExclusiveContext(delays), md, 0, 1, columns=[1],
+                                extra_contexts=[Failing(delays)])
