@@ -628,6 +628,12 @@ int try_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
                 const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done,
                 uint32_t *flag_word = nullptr) {
     *done = false;
+    // ORCD_NO_SPECULATION=1 in the environment: always the general path (for profiles of it)
+    static const bool disabled = [] {
+        const char *e = getenv("ORCD_NO_SPECULATION");
+        return e && *e && *e != '0';
+    }();
+    if (disabled) return ORCD_OK;
     if (num_values < SPEC_MIN_VALUES || (((uintptr_t)d_out) & 15) || n_entries > 0xFFFFFFFFull) return ORCD_OK;
     const uint64_t n_win = (num_values + WINDOW - 1) >> WINDOW_SHIFT;
     const uint64_t n_seg = n_entries ? n_entries : 1;
