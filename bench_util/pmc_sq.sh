@@ -1,12 +1,12 @@
 set +e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/pmc_delta
+O=/tmp/pmc_run
 rm -rf $O; mkdir -p $O
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq -- python3 bench.py --workload ${WL:-delta_w10} --steps 2 --warmup 1 --no-cpu-baseline > $O/sq.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc ${PMC:-SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY} --output-format csv -d $O/sq -- python3 bench.py --workload ${WL:-delta_w10} --steps 2 --warmup 1 --no-cpu-baseline > $O/sq.log 2>&1
 python3 - <<'PY'
 import csv,glob,collections
-f=glob.glob('gpurun_out/pmc_delta/sq/**/*counter_collection.csv',recursive=True)[0]
+f=glob.glob('/tmp/pmc_run/sq/**/*counter_collection.csv',recursive=True)[0]
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k=r['Kernel_Name'].split('(')[0]

@@ -201,6 +201,28 @@ int orcd_rlev2_runs(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num
 
 /* ---- byte-RLE and booleans ------------------------------------------------------------------ */
 
+/* One run of a byte-RLE stream: what BooleanRleRunIter yields as BooleanRun::Run(value, length) or
+ * BooleanRun::Literals(bytes) (src/read/decode/boolean_rle.rs:7-12, 40-63), as positions instead of
+ * copies: the repeated byte, or the first literal byte, is stream[payload_offset]. */
+typedef struct {
+    uint64_t payload_offset; /* offset in the stream of the value byte / of the first literal byte */
+    uint64_t out_offset;     /* index of the run's first byte in the decoded bytes */
+    uint32_t length;         /* decoded bytes: 3..130 for a run, 1..128 for literals */
+    uint32_t is_run;         /* 1: `length` copies of one byte; 0: `length` literal bytes */
+} orcd_byte_run;
+
+#define ORCD_WHOLE_STREAM ((size_t)-1)
+
+/* Replaces BooleanRleRunIter::new(reader) (src/read/decode/boolean_rle.rs:14-63): runs the
+ * control-byte scan only and copies the run table to host memory -- at most `max_runs` entries
+ * into `runs`, the number of runs needed to cover `num_bytes` decoded bytes into `n_runs`, the
+ * decoded bytes those runs hold into `total_bytes` (nullable; the last run may reach past
+ * num_bytes).  num_bytes = ORCD_WHOLE_STREAM: every run of the stream (the reference's iterator
+ * takes no length); a last run that is cut short is ORCD_OUT_OF_SPEC then, as it is an Err there. */
+int orcd_byte_rle_runs(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_bytes,
+                       const uint64_t *entry_points, size_t n_entries, orcd_byte_run *runs,
+                       size_t max_runs, size_t *n_runs, uint64_t *total_bytes, unsigned flags);
+
 /* Replaces BooleanRleRunIter (src/read/decode/boolean_rle.rs:14-63) expanded to its bytes:
  * out[0..num_bytes).  `entry_points`: byte offsets of control bytes, as for orcd_rlev2_decode. */
 int orcd_byte_rle_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_bytes,

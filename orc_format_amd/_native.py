@@ -21,6 +21,14 @@ class OrcdRun(C.Structure):
                 ("bit_width", C.c_uint32), ("length", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class OrcdByteRun(C.Structure):
+    _fields_ = [("payload_offset", C.c_uint64), ("out_offset", C.c_uint64), ("length", C.c_uint32),
+                ("is_run", C.c_uint32)]
+
+
+WHOLE_STREAM = C.c_size_t(-1).value
+
+
 class StripeInfo(C.Structure):
     _fields_ = [("offset", C.c_uint64), ("index_length", C.c_uint64), ("data_length", C.c_uint64),
                 ("footer_length", C.c_uint64), ("number_of_rows", C.c_uint64)]
@@ -64,6 +72,8 @@ SIGNATURES = {
                                             C.POINTER(SZ), C.c_uint]),
     "orcd_rlev2_runs": (C.c_int, [P, P, SZ, SZ, U64P, SZ, C.POINTER(OrcdRun), SZ, C.POINTER(SZ),
                                   C.c_uint]),
+    "orcd_byte_rle_runs": (C.c_int, [P, P, SZ, SZ, U64P, SZ, C.POINTER(OrcdByteRun), SZ, C.POINTER(SZ),
+                                     C.POINTER(C.c_uint64), C.c_uint]),
     "orcd_byte_rle_decode": (C.c_int, [P, P, SZ, SZ, U64P, SZ, P, C.c_uint]),
     "orcd_boolean_decode": (C.c_int, [P, P, SZ, SZ, U64P, SZ, P, P, C.POINTER(C.c_uint64),
                                       C.c_uint]),

@@ -118,6 +118,23 @@ class Context:
         return [(r.kind, r.bit_width, r.length, r.out_offset, r.payload_offset)
                 for r in arr[:min(cap, cnt.value)]]
 
+    def byte_rle_runs(self, stream, num_bytes=None, entry_points=None):
+        """The runs of a byte-RLE stream as a structured array (payload_offset, out_offset, length,
+        is_run) and the number of decoded bytes they hold; num_bytes=None: every run of the stream."""
+        s = _host_u8(stream)
+        e, ne = _entries(entry_points)
+        cap = max(16, s.size)  # a run takes at least two stream bytes
+        arr = np.zeros(cap, dtype=np.dtype([("payload_offset", "<u8"), ("out_offset", "<u8"),
+                                            ("length", "<u4"), ("is_run", "<u4")]))
+        cnt, total = C.c_size_t(0), C.c_uint64(0)
+        rc = self._lib.orcd_byte_rle_runs(self._h, s.ctypes.data, s.size,
+                                          N.WHOLE_STREAM if num_bytes is None else num_bytes,
+                                          e.ctypes.data if ne else None, ne,
+                                          C.cast(arr.ctypes.data, C.POINTER(N.OrcdByteRun)), cap,
+                                          C.byref(cnt), C.byref(total), 0)
+        check(rc, self._h)
+        return arr[:min(cap, cnt.value)], int(total.value)
+
     def byte_rle(self, stream, num_bytes, entry_points=None):
         s = _host_u8(stream)
         e, ne = _entries(entry_points)

@@ -694,9 +694,12 @@ struct ByteRleTable {
 };
 
 // Builds the run table of one byte-RLE stream that is already on the device.
+// whole_stream: every run the stream holds is wanted, however many bytes that makes (num_bytes is
+// then the largest number there is, and running out of stream before it is no error).
 int byte_rle_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_bytes,
                    const uint64_t *d_entries, size_t n_entries, ByteRleTable *t,
-                   const uint64_t *d_seg_ends = nullptr, SegTable *seg_table = nullptr) {
+                   const uint64_t *d_seg_ends = nullptr, SegTable *seg_table = nullptr,
+                   bool whole_stream = false, uint64_t *total_bytes = nullptr) {
     if (n_entries > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
@@ -711,7 +714,10 @@ int byte_rle_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_
     }, &sr));
     mark(c, 1);
     if (seg_table) *seg_table = sr.table;
-    if (sr.totals.error) return (int)sr.totals.error;
+    // (no segment named: no walk stopped early, the stream just holds fewer bytes than asked for)
+    const bool only_short = sr.totals.error == ORCD_OUT_OF_SPEC && sr.totals.error_seg == 0xFFFFFFFFu;
+    if (sr.totals.error && !(whole_stream && only_short)) return (int)sr.totals.error;
+    if (total_bytes) *total_bytes = sr.totals.total_vals;
     if (sr.totals.total_runs >= 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
     const size_t n_slots = byte_rle_window_slots(sr.totals.total_vals);
     if (n_slots > 0xFFFFFFFFull) return ORCD_UNSUPPORTED;
@@ -1220,6 +1226,53 @@ int orcd_rlev2_runs(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_v
 } ORCD_CATCH
 
 // ---- byte-RLE and booleans ------------------------------------------------------------------
+
+int orcd_byte_rle_runs(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_bytes,
+                       const uint64_t *entry_points, size_t n_entries, orcd_byte_run *runs,
+                       size_t max_runs, size_t *n_runs, uint64_t *total_bytes, unsigned flags) try {
+    if (!c || (len && !stream) || !n_runs || (max_runs && !runs) || (n_entries && !entry_points))
+        return ORCD_INVALID_ARGUMENT;
+    *n_runs = 0;
+    if (total_bytes) *total_bytes = 0;
+    if (num_bytes == 0 || len == 0) return num_bytes == 0 || num_bytes == ORCD_WHOLE_STREAM ? ORCD_OK : ORCD_OUT_OF_SPEC;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE;
+    mark(c, 0);
+    const void *d_stream, *d_entries;
+    ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t),
+                      in_dev && !(flags & ORCD_ENTRIES_HOST), &d_entries));
+    ByteRleTable t;
+    uint64_t held = 0;
+    ORCD_TRY(byte_rle_table(c, (const uint8_t *)d_stream, len, num_bytes, (const uint64_t *)d_entries,
+                            n_entries, &t, nullptr, nullptr, num_bytes == ORCD_WHOLE_STREAM, &held));
+    std::vector<ByteRun> h((size_t)t.n_runs);
+    if (!h.empty()) {
+        hipError_t e = hipMemcpyAsync(h.data(), t.runs, h.size() * sizeof(ByteRun), hipMemcpyDeviceToHost,
+                                      c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            c->last_hip = e;
+            return ORCD_HIP_ERROR;
+        }
+    }
+    size_t count = 0;
+    uint64_t covered = 0;
+    for (size_t i = 0; i < h.size() && h[i].out_off < num_bytes; i++, count++) {
+        const uint32_t n = (uint32_t)((h[i].src >> 40) & 0xFF) + 1;
+        if (count < max_runs) {
+            runs[count].payload_offset = h[i].src & ((1ull << 40) - 1);
+            runs[count].out_offset = h[i].out_off;
+            runs[count].length = n;
+            runs[count].is_run = (h[i].src >> 48) & 1;
+        }
+        covered = h[i].out_off + n;
+    }
+    *n_runs = count;
+    if (total_bytes) *total_bytes = covered;
+    return ORCD_OK;
+} ORCD_CATCH
 
 int orcd_byte_rle_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_bytes,
                          const uint64_t *entry_points, size_t n_entries, uint8_t *out,

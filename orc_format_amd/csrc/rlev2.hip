@@ -361,6 +361,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
                 // the window's own copy, so that the value kernel needs no dependent table load
                 RunEntry ge = e;
                 if (single) ge.desc |= DESC_SINGLE;
+                else ge.base = run_idx;  // a shared window: where its runs start in the table
                 group_run[win] = ge;
             }
             out_off += r.len;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
             RunEntry e;
             e.desc = make_desc(pos, KIND_SHORT_REPEAT, 0, 1, 0, 1);
             e.out_off = out_off;
-            e.base = 0;
+            e.base = run_idx;
             e.aux = 0;
             runs[run_idx] = e.desc;
             // Windows in which no run starts exist only at the tail: the last run may reach
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(256) void rlev2_emit_staged_kernel(
             RunEntry ge;
             ge.desc = single ? desc | DESC_SINGLE : desc;
             ge.out_off = out_off;
-            ge.base = r.base;
+            ge.base = single ? r.base : run_idx;  // a shared window: where its runs start in the table
             ge.aux = r.aux;
             group_run[win] = ge;
         }
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(256) void rlev2_emit_staged_kernel(
             RunEntry e;
             e.desc = make_desc(pos, KIND_SHORT_REPEAT, 0, 1, 0, 1);
             e.out_off = end_off;
-            e.base = 0;
+            e.base = end_idx;
             e.aux = 0;
             runs[end_idx] = e.desc;
             const uint64_t g_end = (end_off + WINDOW - 1) >> WINDOW_SHIFT;
@@ -763,9 +764,14 @@ struct Wave {
     mutable uint64_t acc;
     mutable uint32_t saw_patched;  // MODE_SUMS: a PatchedBase run was met (its patches are not summed)
 };
-template <int M>
+// SHORT: the kernel variant for columns of short runs (many runs per window), compiled for fewer
+// wavefronts per SIMD and more registers each; only there does a batch of runs without running
+// sums take the lane-per-eight-values path (expand_window_by_lane), whose registers the variant
+// for long runs, which wants all eight wavefronts to saturate HBM, cannot afford.
+template <int M, bool SHORT = false>
 struct WaveOf : Wave {
     static constexpr int MODE = M;
+    static constexpr bool BY_LANE = SHORT;
 };
 
 // Copies stream bytes [b0, b1) into the LDS slice; returns the stream offset that LDS byte 0
@@ -1162,27 +1168,154 @@ struct RunFields {
     uint32_t rel_out;  // out_off relative to the batch's first value
 };
 
-// `batch_beg`: index in the output of the batch's first value.  Returns the index after its last.
+// One window of a batch whose runs carry no running sum (ShortRepeat, Direct, Delta without packed
+// deltas: each value follows from its run's fields and its index in the run).  Lane i computes the
+// eight consecutive values 8 i .. 8 i + 7 of the window: it looks its first value's run up once
+// (a binary search over the lanes, which hold one run each) and then walks along the runs, so that
+// a run's fields are fetched once per lane and run rather than once per value; the eight values go
+// through the wavefront's LDS slice -- free again once the packed bytes have been read -- into the
+// layout of the stores (lane i of step j: values 128 j + 2 i, + 1).
+//   my_rel / my_kw / my_bit / my_base / my_aux: lane k's run -- first value relative to the batch,
+//   kind | width << 2 | (length - 1) << 9, LDS bit position of its packed field 0, base, step.
+template <class W>
+__device__ __forceinline__ void expand_window_by_lane(const W &wv, uint64_t wbase, uint64_t lo, uint64_t hi,
+                                                      uint64_t batch_beg, uint32_t my_rel, uint32_t my_kw,
+                                                      uint32_t my_bit, uint64_t my_base, uint64_t my_aux,
+                                                      bool any_linear, bool wide) {
+    const int lane = wv.lane;
+    // positions relative to the batch's first value, as signed numbers (the window may start before it)
+    const int32_t first = (int32_t)(int64_t)(wbase + 8u * (uint32_t)lane - batch_beg);
+    const int32_t lo_rel = (int32_t)(int64_t)(lo - batch_beg), hi_rel = (int32_t)(int64_t)(hi - batch_beg);
+    // the run of this lane's first wanted value: largest k with rel_out[k] <= it (lanes without
+    // a run hold 0xFFFFFFFF)
+    const uint32_t seek = (uint32_t)(first > lo_rel ? first : lo_rel);
+    int k = 0;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        const uint32_t v = __shfl(my_rel, k + sft);
+        if (v <= seek) k += sft;
+    }
+    uint32_t cur_rel, cur_kw, cur_bit;
+    uint64_t cur_base = 0, cur_aux = 0;
+    auto fetch = [&]() {
+        cur_rel = __shfl(my_rel, k);
+        cur_kw = __shfl(my_kw, k);
+        cur_bit = __shfl(my_bit, k);
+        if (any_linear) {
+            cur_base = shfl64(my_base, k);
+            cur_aux = shfl64(my_aux, k);
+        }
+    };
+    fetch();
+    // (one call per slot, written out: a loop with the inner loop below in it is not unrolled by
+    // the compiler, and v[] indexed by a loop variable would live in scratch memory)
+    uint64_t v[8];
+    auto slot = [&](const int t) __attribute__((always_inline)) {
+        const int32_t s_rel = first + t;
+        const bool act = s_rel >= lo_rel && s_rel < hi_rel;
+        // on to the next run where this value lies past the current one (runs of one or two
+        // values: more than once)
+        while (__ballot(act && (uint32_t)s_rel >= cur_rel + (cur_kw >> 9) + 1u) != 0) {
+            if (act && (uint32_t)s_rel >= cur_rel + (cur_kw >> 9) + 1u) k = (k + 1) & 63;
+            fetch();
+        }
+        const uint32_t idx = (uint32_t)s_rel - cur_rel, kind = cur_kw & 3u, w = (cur_kw >> 2) & 127u;
+        uint64_t val;
+        if (any_linear && kind == KIND_DELTA) {
+            val = cur_base + (uint64_t)idx * cur_aux;
+        } else {
+            // a packed field of a Direct run, or the one field a ShortRepeat run consists of
+            const uint32_t bit = act ? cur_bit + (kind == KIND_DIRECT ? idx * w : 0u) : 0u;  // (inactive lanes read inside the slice)
+            const uint64_t m = wide ? lds_bits64(wv.lds, bit, w ? w : 1u) : (uint64_t)lds_bits32(wv.lds, bit, w ? w : 1u);
+            val = wv.is_signed ? zigzag(m) : m;
+        }
+        return val;
+    };
+    v[0] = slot(0);
+    v[1] = slot(1);
+    v[2] = slot(2);
+    v[3] = slot(3);
+    v[4] = slot(4);
+    v[5] = slot(5);
+    v[6] = slot(6);
+    v[7] = slot(7);
+    // registers -> LDS -> the layout of the stores.  Pairs (2 p, 2 p + 1) of lane i go to 16-byte
+    // slot 64 p + i (neighbouring lanes, neighbouring slots); lane i of step j wants the pair
+    // 2 (i & 3) of lane 16 j + (i >> 2).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every read of the packed bytes is done
+    u64x2 *tile = (u64x2 *)wv.lds;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        u64x2 pair;
+        pair.x = v[2 * p];
+        pair.y = v[2 * p + 1];
+        tile[64 * p + lane] = pair;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const u64x2 pair = tile[64 * (lane & 3) + 16 * j + (lane >> 2)];
+        const uint64_t e0 = wbase + 128u * j + 2u * (uint32_t)lane;
+        store_pair(wv, e0, pair.x, pair.y, e0 >= lo && e0 < hi, e0 + 1 >= lo && e0 + 1 < hi);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the slice may be staged into again
+}
+
+// The runs rb, rb + 1, ... of the table that start before `own_end` (the end of the wavefront's
+// window), at most 64 of them and `avail` (what the table holds from rb on); `batch_beg`: index in
+// the output of the first one's first value.  Returns the index after the last one's last value,
+// and in `nb` how many runs that were.
 template <class W>
 __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t *runs, uint32_t rb,
-                                                     uint32_t nb, const uint64_t batch_beg) {
+                                                     uint32_t avail, const uint64_t batch_beg,
+                                                     const uint64_t own_end, uint32_t &nb) {
     const int lane = wv.lane;
     // lane k holds run rb + k of the batch: its descriptor from the table, its place in the
-    // output from a prefix sum of the lengths, its base / second field from its header
+    // output from a prefix sum of the lengths, its base / second field from its header.  The
+    // table's slots past the window's runs may never have been written: a run that turns out to
+    // start at or after own_end is not looked at any further (lengths are 1..512 whatever the
+    // bits, so the places of the runs before it do not depend on it).
     RunEntry me;
     me.desc = make_desc(0, KIND_SHORT_REPEAT, 0, 1, 0, 1);
     me.base = 0;
     me.aux = 0;
-    const bool mine = (uint32_t)lane < nb;
-    if (mine) me.desc = runs[rb + lane];
+    const bool held = (uint32_t)lane < avail;
+    if (held) me.desc = runs[rb + lane];
+    const uint32_t incl_all = wave_scan_u32(held ? desc_len(me.desc) : 0u, lane);
+    const bool mine = held && batch_beg + (incl_all - desc_len(me.desc)) < own_end;
+    nb = (uint32_t)__builtin_popcountll(__ballot(mine));
+    if (nb == 0) return batch_beg;
+    if (!mine) me.desc = make_desc(0, KIND_SHORT_REPEAT, 0, 1, 0, 1);
     const uint32_t my_kind = desc_kind(me.desc), my_w = desc_width(me.desc);
     const uint32_t my_len = desc_len(me.desc);
-    const uint32_t incl = wave_scan_u32(mine ? my_len : 0u, lane);
+    const uint32_t incl = mine ? incl_all : 0u;
     const uint32_t my_rel = mine ? incl - my_len : 0xFFFFFFFFu;
-    const uint64_t batch_all = batch_beg + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint64_t batch_all = batch_beg + readlane32(incl_all, (int)nb - 1);
     uint64_t batch_end = batch_all < wv.num_values ? batch_all : wv.num_values;
     if (batch_beg >= batch_end) return batch_all;  // every run of the batch lies after the last wanted value
-    if (mine && my_kind != KIND_DIRECT) {
+    // no run of the batch carries a running sum or patches: expand_window_by_lane does the windows,
+    // and reads the value of a ShortRepeat run from the staged bytes like a packed field
+    const bool by_lane = W::BY_LANE && __ballot(mine && !(my_kind == KIND_SHORT_REPEAT || my_kind == KIND_DIRECT ||
+                                            (my_kind == KIND_DELTA && my_w == 0))) == 0;
+    bool have_repeats = !by_lane;
+    auto load_repeats = [&]() {
+        // the repeated value: width / 8 bytes, most significant first, right behind the header byte
+        // (rle_v2.rs:283-301); the header scan has checked that they lie inside the stream
+        if (mine && my_kind == KIND_SHORT_REPEAT) {
+            const uint64_t pay = desc_payload(me.desc);
+            const uint8_t *p = wv.s + pay;
+            const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
+            if (my_w >= 8 && pay + (my_w >> 3) <= wv.len) {
+                const uint64_t v = global_bits((const uint32_t *)(p - sk), (uint64_t)sk * 8, my_w);
+                me.base = wv.is_signed ? zigzag(v) : v;
+            }
+        }
+    };
+    if (!by_lane) load_repeats();
+    if (mine && my_kind != KIND_DIRECT && my_kind != KIND_SHORT_REPEAT) {
         // the header scan accepted this header: the parse cannot fail, and reads what it read
         const uint64_t pos = desc_payload(me.desc) - desc_header_bytes(me.desc);
         ParsedRun r;
@@ -1194,6 +1327,10 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
         }
     }
     uint64_t carry = 0;  // running value of a Delta run that continues into the next step
+    const bool any_linear = __ballot(mine && my_kind == KIND_DELTA) != 0;
+    const bool wide = __ballot(mine && my_kind != KIND_DELTA && my_w > 32) != 0;
+    const uint32_t my_kw = my_kind | (my_w << 2) | ((my_len - 1) << 9);
+    const uint32_t last_rel = readlane32(my_rel, (int)nb - 1);  // where the batch's last run starts
 
     for (uint64_t wbase = (batch_beg >> WINDOW_SHIFT) << WINDOW_SHIFT; wbase < batch_end;
          wbase += WINDOW) {
@@ -1205,7 +1342,12 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
         bool needs = false, scans = false;
         // (positions relative to the batch's first value fit 32 bits: 64 runs of at most 512)
         const uint32_t lo_rel = (uint32_t)(lo - batch_beg), hi_rel = (uint32_t)(hi - batch_beg);
-        if ((uint32_t)lane < nb && my_rel < hi_rel && my_rel + my_len > lo_rel &&
+        if (by_lane && mine && my_kind == KIND_SHORT_REPEAT && my_rel < hi_rel && my_rel + my_len > lo_rel) {
+            // the repeated value's bytes are staged like a packed field (of which it is one)
+            needs = true;
+            need_b0 = desc_payload(me.desc);
+            need_b1 = need_b0 + (my_w >> 3);
+        } else if ((uint32_t)lane < nb && my_rel < hi_rel && my_rel + my_len > lo_rel &&
             my_kind != KIND_SHORT_REPEAT && my_w != 0) {
             const uint32_t first = my_rel >= lo_rel ? 0u : lo_rel - my_rel;
             const uint32_t last = (my_rel + my_len) <= hi_rel ? my_len : hi_rel - my_rel;
@@ -1232,7 +1374,38 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
             }
         }
 
+        if (by_lane && W::MODE == MODE_VALUES && lo_rel >= last_rel && (use_lds || need_mask == 0)) {
+            // what is wanted of this window lies in the batch's last run (its tail, reaching over
+            // from the window before): lane i takes values lo + i, lo + i + 64, ... of it
+            const uint32_t kw = my_kind | (my_w << 2);
+            const uint32_t t_kw = readlane32(kw, (int)nb - 1);
+            const uint32_t t_bit = readlane32(((uint32_t)desc_payload(me.desc) - (uint32_t)lds_origin) << 3, (int)nb - 1);
+            const uint64_t t_base = readlane64(me.base, (int)nb - 1), t_aux = readlane64(me.aux, (int)nb - 1);
+            const uint32_t t_kind = t_kw & 3u, t_w = t_kw >> 2;
+            for (uint32_t r = lo_rel + (uint32_t)lane; r < hi_rel; r += 64) {
+                const uint32_t idx = r - last_rel;
+                uint64_t val = t_base + (uint64_t)idx * t_aux;  // Delta without packed deltas
+                if (t_kind != KIND_DELTA) {
+                    const uint64_t m = lds_bits64(wv.lds, t_bit + (t_kind == KIND_DIRECT ? idx * t_w : 0u), t_w);
+                    val = wv.is_signed ? zigzag(m) : m;
+                }
+                stream_store1(wv.out + batch_beg + r, val);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the slice may be staged into again
+            continue;
+        }
+        if (by_lane && (use_lds || need_mask == 0)) {
+            const uint32_t my_bit = ((uint32_t)desc_payload(me.desc) - (uint32_t)lds_origin) << 3;
+            expand_window_by_lane(wv, wbase, lo, hi, batch_beg, my_rel, my_kw, my_bit, me.base, me.aux,
+                                  any_linear, wide);
+            continue;
+        }
         // ---- decode the window: 4 steps of 128 values -------------------------------------
+        if (!have_repeats) {  // (wave-uniform)
+            load_repeats();
+            have_repeats = true;
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint64_t e0 = wbase + 128u * j + 2u * lane;
@@ -1357,8 +1530,8 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
 // window g; bit 2 of *flags is raised when a PatchedBase run was met, whose patches are not part of
 // the sums.  MODE_OFFSETS: group_sums[g] holds the sum of all values before group g, and out[i]
 // receives the sum of the values before i.
-template <int MODE>
-__global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
+template <int MODE, bool SHORT>
+__global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ runs,
     const uint32_t *__restrict__ group_first, const RunEntry *__restrict__ group_run,
     uint32_t n_groups, uint32_t n_runs, uint64_t num_values, int is_signed,
@@ -1375,7 +1548,7 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
     }
     const uint32_t g = wg * VAL_WAVES + wave;
     if (g >= n_groups) return;  // whole wavefront leaves; no workgroup barrier is used below
-    WaveOf<MODE> wv;
+    WaveOf<MODE, SHORT> wv;
     wv.s = s;
     wv.lds = stage[wave];
     wv.out = out;
@@ -1398,15 +1571,17 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_values_kernel(
         decode_single_run(wv, desc, readfirstlane64(e->out_off), readfirstlane64(e->base),
                           readfirstlane64(e->aux));
     } else {
-        // the group's runs; clamped to the table so that a bad index can never walk off it
-        uint32_t r1 = __builtin_amdgcn_readfirstlane(group_first[g + 1]);
-        if (r1 > n_runs) r1 = n_runs;
-        uint32_t r0 = __builtin_amdgcn_readfirstlane(group_first[g]);
-        if (r0 > r1) r0 = r1;
+        // the runs that start inside this window, 64 at a time from the first one, whose index
+        // the window's copy carries (clamped to the table so that a bad index can never walk off
+        // it); which run is the last follows from the lengths
         uint64_t beg = readfirstlane64(e->out_off);  // where the group's first run starts
-        for (uint32_t rb = r0; rb < r1; rb += 64) {
-            const uint32_t nb = (r1 - rb) < 64u ? (r1 - rb) : 64u;
-            beg = decode_run_batch(wv, runs, rb, nb, beg);
+        const uint64_t own_end = ((uint64_t)g + 1) << WINDOW_SHIFT;
+        uint64_t r0 = readfirstlane64(e->base);
+        if (r0 > n_runs) r0 = n_runs;
+        for (uint32_t rb = (uint32_t)r0; rb < n_runs && beg < own_end; rb += 64) {
+            uint32_t nb;
+            beg = decode_run_batch(wv, runs, rb, n_runs - rb, beg, own_end, nb);
+            if (nb < 64) break;
         }
     }
     if (MODE == MODE_SUMS) {
@@ -1677,9 +1852,15 @@ static hipError_t launch_values_mode(hipStream_t st, const Rlev2Table &t, int64_
                                      uint64_t *group_sums, uint32_t *flags) {
     if (t.n_groups == 0) return hipSuccess;
     const uint32_t blocks = (t.n_groups + VAL_WAVES - 1) / VAL_WAVES;
-    rlev2_values_kernel<MODE><<<blocks, VAL_WAVES * 64, 0, st>>>(
-        t.stream, t.len, t.runs, t.group_first, t.group_run, t.n_groups, t.n_runs, t.num_values,
-        t.is_signed, out, group_sums, flags);
+    // more than two runs per window on average: the variant for short runs
+    if ((uint64_t)t.n_runs > 2ull * t.n_groups)
+        rlev2_values_kernel<MODE, true><<<blocks, VAL_WAVES * 64, 0, st>>>(
+            t.stream, t.len, t.runs, t.group_first, t.group_run, t.n_groups, t.n_runs, t.num_values,
+            t.is_signed, out, group_sums, flags);
+    else
+        rlev2_values_kernel<MODE, false><<<blocks, VAL_WAVES * 64, 0, st>>>(
+            t.stream, t.len, t.runs, t.group_first, t.group_run, t.n_groups, t.n_runs, t.num_values,
+            t.is_signed, out, group_sums, flags);
     return hipGetLastError();
 }
 

@@ -160,40 +160,57 @@ class BooleanIter:
 
 
 class BooleanRun:
-    """BooleanRun (boolean_rle.rs:9-12): `Run(value, length)` or `Literals(bytes)`."""
+    """BooleanRun (boolean_rle.rs:7-12): `Run(value, length)` -- is_run, payload = (byte, length)
+    -- or `Literals(bytes)` -- payload = the literal bytes."""
 
     def __init__(self, is_run, payload):
         self.is_run = is_run
         self.payload = payload
 
+    def __eq__(self, other):
+        return isinstance(other, BooleanRun) and (self.is_run, self.payload) == (other.is_run, other.payload)
+
+    def __repr__(self):
+        return ("Run(%d, %d)" % self.payload) if self.is_run else "Literals(%r)" % (self.payload,)
+
+    @staticmethod
+    def Run(value, length):
+        return BooleanRun(True, (value, length))
+
+    @staticmethod
+    def Literals(data):
+        return BooleanRun(False, bytes(data))
+
 
 class BooleanRleRunIter:
     """BooleanRleRunIter::new(reader) (boolean_rle.rs:14-63): the byte-RLE runs of the stream.
-    The bytes come from the GPU byte-RLE decoder; run boundaries are re-read from the control
-    bytes on the host only to label them."""
+    Two GPU calls on first use, whatever the number of runs: the control-byte scan, whose run
+    table says where every run starts in the decoded bytes, and the byte-RLE decode.  A stream
+    whose last run is cut short raises OutOfSpec (an Err item there); unlike the reference's
+    iterator, which yields an Err forever once the reader is empty, this one stops at the end."""
 
-    def __init__(self, reader, ctx=None):
-        self._reader = bytes(reader)
+    def __init__(self, reader, ctx=None, entry_points=None):
+        self._reader = reader
         self._ctx = ctx or default_context()
+        self._entries = entry_points
+        self._table = None
         self._pos = 0
 
     def __iter__(self):
         return self
 
     def __next__(self):
-        if self._pos >= len(self._reader):
+        if self._table is None:
+            self._table, total = self._ctx.byte_rle_runs(self._reader, None, self._entries)
+            self._bytes = self._ctx.byte_rle(self._reader, total, self._entries) if total else b""
+        if self._pos >= len(self._table):
             raise StopIteration
-        control = self._reader[self._pos]
-        if control < 128:
-            n, used = control + 3, 2
-        else:
-            n, used = 256 - control, 1 + 256 - control
-        chunk = self._reader[self._pos:self._pos + used]
-        data = self._ctx.byte_rle(chunk, n)
-        self._pos += used
-        if control < 128:
-            return BooleanRun(True, (int(data[0]), n))
-        return BooleanRun(False, bytes(data))
+        r = self._table[self._pos]
+        self._pos += 1
+        off, n = int(r["out_offset"]), int(r["length"])
+        if r["is_run"]:
+            return BooleanRun.Run(int(self._bytes[off]), n)
+        return BooleanRun.Literals(self._bytes[off:off + n])
 
     def into_inner(self):
         return self._reader
@@ -229,19 +246,17 @@ class FloatIter:
 
 class Values:
     """Values::new(reader, scratch) (variable_length.rs:5-28): `next(length)` returns the next
-    `length` bytes of the stream."""
+    `length` bytes of the stream -- fewer when the stream runs dry, without an error, as
+    `take(length).read_to_end` does there (the string decoders check the total against the DATA
+    stream's length instead)."""
 
     def __init__(self, reader, scratch=None):
         self._reader = memoryview(bytes(reader))
         self._pos = 0
 
     def next(self, length):
-        from ..error import OrcError
-        from .. import _native as N
-        if length > len(self._reader) - self._pos:
-            raise OrcError(N.OUT_OF_SPEC)
         out = self._reader[self._pos:self._pos + length]
-        self._pos += length
+        self._pos += len(out)
         return bytes(out)
 
     def into_inner(self):

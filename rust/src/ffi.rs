@@ -71,6 +71,20 @@ pub struct orcd_run {
     pub reserved: u32,
 }
 
+/// One run of a byte-RLE stream (include/orcd.h; BooleanRun of src/read/decode/boolean_rle.rs:7-12
+/// as positions in the stream and in the decoded bytes).
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct orcd_byte_run {
+    pub payload_offset: u64,
+    pub out_offset: u64,
+    pub length: u32,
+    pub is_run: u32,
+}
+
+/// `num_bytes` of `orcd_byte_rle_runs` that asks for every run of the stream.
+pub const ORCD_WHOLE_STREAM: usize = usize::MAX;
+
 /// proto::StripeInformation (src/proto.rs:206-217)
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
@@ -131,6 +145,10 @@ extern "C" {
     pub fn orcd_rlev2_runs(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_values: usize,
                            entry_points: *const u64, n_entries: usize, runs: *mut orcd_run,
                            max_runs: usize, n_runs: *mut usize, flags: c_uint) -> c_int;
+    pub fn orcd_byte_rle_runs(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_bytes: usize,
+                              entry_points: *const u64, n_entries: usize, runs: *mut orcd_byte_run,
+                              max_runs: usize, n_runs: *mut usize, total_bytes: *mut u64,
+                              flags: c_uint) -> c_int;
     pub fn orcd_byte_rle_decode(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_bytes: usize,
                                 entry_points: *const u64, n_entries: usize, out: *mut u8,
                                 flags: c_uint) -> c_int;

@@ -71,6 +71,29 @@ def test_rust_binding_declares_the_header():
     assert c_structs == r_structs, (c_structs, r_structs)
 
 
+def test_rust_shim_exports_every_name_of_the_decode_module():
+    """rust/src/lib.rs declares every public name of the crate's read::decode module
+    (src/read/decode/mod.rs:8-14) and uses only entry points that ffi.rs declares."""
+    names = ["BooleanIter", "BooleanRleRunIter", "BooleanRun", "Float", "FloatIter",
+             "SignedRleV2Iter", "SignedRleV2Run", "SignedRleV2RunIter", "UnsignedRleV2Iter",
+             "UnsignedRleV2Run", "UnsignedRleV2RunIter", "Values"]
+    with open(os.path.join(ROOT, "rust", "src", "lib.rs")) as f:
+        shim = re.sub(r"//.*", "", f.read())
+    declared = set(re.findall(r"\bpub (?:struct|enum|trait) ([A-Za-z0-9]+)", shim))
+    assert set(names) <= declared, set(names) - declared
+    with open(os.path.join(ROOT, "rust", "src", "ffi.rs")) as f:
+        ffi = f.read()
+    for used in set(re.findall(r"ffi::(orcd_[a-z0-9_]+)", shim)):
+        assert re.search(r"\b(fn|struct) %s\b" % used, ffi), used
+    for used in set(re.findall(r"ffi::(ORCD_[A-Z0-9_]+)", shim)):
+        assert re.search(r"pub const %s\b" % used, ffi), used
+    # the run enums have the crate's variants, and len() like its run types
+    for enum in ("UnsignedRleV2Run", "SignedRleV2Run"):
+        body = re.search(r"pub enum %s \{(.*?)\}" % enum, shim, flags=re.S).group(1)
+        assert {"Direct", "Delta", "ShortRepeat"} <= set(re.findall(r"\b([A-Z][A-Za-z]+)\(", body))
+    assert shim.count("pub fn len(&self)") >= 4
+
+
 def test_strerror():
     assert N.lib().orcd_strerror(1) == b"out of spec"
     assert N.lib().orcd_strerror(0) == b"ok"
