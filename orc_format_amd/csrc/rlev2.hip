@@ -754,6 +754,7 @@ struct Wave {
     const uint8_t *s;      // stream
     uint64_t len;          // its length: no load of the kernel may start at or after s + len
     uint32_t *lds;         // this wavefront's staging slice
+    uint32_t *marks;       // 16 words of LDS of its own: one bit per value of a window
     int64_t *out;
     uint64_t num_values;
     int lane;
@@ -764,14 +765,9 @@ struct Wave {
     mutable uint64_t acc;
     mutable uint32_t saw_patched;  // MODE_SUMS: a PatchedBase run was met (its patches are not summed)
 };
-// SHORT: the kernel variant for columns of short runs (many runs per window), compiled for fewer
-// wavefronts per SIMD and more registers each; only there does a batch of runs without running
-// sums take the lane-per-eight-values path (expand_window_by_lane), whose registers the variant
-// for long runs, which wants all eight wavefronts to saturate HBM, cannot afford.
-template <int M, bool SHORT = false>
+template <int M>
 struct WaveOf : Wave {
     static constexpr int MODE = M;
-    static constexpr bool BY_LANE = SHORT;
 };
 
 // Copies stream bytes [b0, b1) into the LDS slice; returns the stream offset that LDS byte 0
@@ -1168,100 +1164,198 @@ struct RunFields {
     uint32_t rel_out;  // out_off relative to the batch's first value
 };
 
-// One window of a batch whose runs carry no running sum (ShortRepeat, Direct, Delta without packed
-// deltas: each value follows from its run's fields and its index in the run).  Lane i computes the
-// eight consecutive values 8 i .. 8 i + 7 of the window: it looks its first value's run up once
-// (a binary search over the lanes, which hold one run each) and then walks along the runs, so that
-// a run's fields are fetched once per lane and run rather than once per value; the eight values go
-// through the wavefront's LDS slice -- free again once the packed bytes have been read -- into the
-// layout of the stores (lane i of step j: values 128 j + 2 i, + 1).
-//   my_rel / my_kw / my_bit / my_base / my_aux: lane k's run -- first value relative to the batch,
-//   kind | width << 2 | (length - 1) << 9, LDS bit position of its packed field 0, base, step.
-template <class W>
-__device__ __forceinline__ void expand_window_by_lane(const W &wv, uint64_t wbase, uint64_t lo, uint64_t hi,
-                                                      uint64_t batch_beg, uint32_t my_rel, uint32_t my_kw,
-                                                      uint32_t my_bit, uint64_t my_base, uint64_t my_aux,
-                                                      bool any_linear, bool wide) {
+// ---- batches of runs that carry no running sum: a lane per eight values ---------------------------
+//
+// ShortRepeat, Direct and Delta runs without packed deltas: each value follows from its run's
+// fields and its index in the run.  Every run of a batch starts inside the wavefront's own window,
+// which is decoded with lane i computing the eight consecutive values 8 i .. 8 i + 7.  Which run a
+// value belongs to is counted, not searched: each run sets the bit of its first value in a 512-bit
+// mask in LDS, lane i reads the mask's byte i, a prefix sum of the bytes' bit counts over the
+// lanes gives the number of runs that start before the lane's values, and the bits of the byte
+// below and at a value give the rest.  The run's fields then come in one 32-bit word from the lane
+// that holds the run; the value of a ShortRepeat run is read from the staged bytes like a packed
+// field (of which it is one).  The eight values go through the wavefront's LDS slice -- free again
+// once the packed bytes have been read -- into the layout of the stores (lane i of step j: values
+// 128 j + 2 i, + 1).
+//   my_ws:  first value of lane k's run relative to the window (>= 512: the lane holds no run)
+//   my_rec: my_ws | byte in the slice of the run's packed field 0 << 9 | width << 22 | kind << 29
+//   lo_w / hi_w: the part of the window that this batch holds, relative to the window
+template <bool WIDE, bool LINEAR, bool SIGNED, class W>
+__device__ __forceinline__ void expand_window_by_marks(const W &wv, uint64_t wbase, uint32_t lo_w, uint32_t hi_w,
+                                                       uint32_t my_ws, uint32_t my_rec, uint64_t my_base,
+                                                       uint64_t my_aux) {
     const int lane = wv.lane;
-    // positions relative to the batch's first value, as signed numbers (the window may start before it)
-    const int32_t first = (int32_t)(int64_t)(wbase + 8u * (uint32_t)lane - batch_beg);
-    const int32_t lo_rel = (int32_t)(int64_t)(lo - batch_beg), hi_rel = (int32_t)(int64_t)(hi - batch_beg);
-    // the run of this lane's first wanted value: largest k with rel_out[k] <= it (lanes without
-    // a run hold 0xFFFFFFFF)
-    const uint32_t seek = (uint32_t)(first > lo_rel ? first : lo_rel);
-    int k = 0;
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) {
-        const uint32_t v = __shfl(my_rel, k + sft);
-        if (v <= seek) k += sft;
-    }
-    uint32_t cur_rel, cur_kw, cur_bit;
-    uint64_t cur_base = 0, cur_aux = 0;
-    auto fetch = [&]() {
-        cur_rel = __shfl(my_rel, k);
-        cur_kw = __shfl(my_kw, k);
-        cur_bit = __shfl(my_bit, k);
-        if (any_linear) {
-            cur_base = shfl64(my_base, k);
-            cur_aux = shfl64(my_aux, k);
-        }
-    };
-    fetch();
-    // (one call per slot, written out: a loop with the inner loop below in it is not unrolled by
-    // the compiler, and v[] indexed by a loop variable would live in scratch memory)
+    if (lane < 16) wv.marks[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (my_ws < WINDOW) atomicOr(&wv.marks[my_ws >> 5], 1u << (my_ws & 31));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t starts = ((const uint8_t *)wv.marks)[lane];  // bit t: a run starts at value 8 lane + t
+    const uint32_t n_starts = (uint32_t)__builtin_popcount(starts);
+    // index of the run that holds the value in front of this lane's first (-1: none does)
+    const uint32_t k_before = wave_scan_dpp(n_starts) - n_starts - 1u;
     uint64_t v[8];
-    auto slot = [&](const int t) __attribute__((always_inline)) {
-        const int32_t s_rel = first + t;
-        const bool act = s_rel >= lo_rel && s_rel < hi_rel;
-        // on to the next run where this value lies past the current one (runs of one or two
-        // values: more than once)
-        while (__ballot(act && (uint32_t)s_rel >= cur_rel + (cur_kw >> 9) + 1u) != 0) {
-            if (act && (uint32_t)s_rel >= cur_rel + (cur_kw >> 9) + 1u) k = (k + 1) & 63;
-            fetch();
-        }
-        const uint32_t idx = (uint32_t)s_rel - cur_rel, kind = cur_kw & 3u, w = (cur_kw >> 2) & 127u;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const uint32_t p = 8u * (uint32_t)lane + (uint32_t)t;
+        const bool act = p - lo_w < hi_w - lo_w;  // lo_w <= p < hi_w
+        const uint32_t k = k_before + (uint32_t)__builtin_popcount(starts & ((2u << t) - 1u));
+        const uint32_t rec = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(k << 2), (int)my_rec);
+        const uint32_t w = (rec >> 22) & 127u, kind = rec >> 29;
+        const uint32_t idx = p - (rec & 511u);
+        // (lanes with nothing to read look at bit 0 of the slice)
+        uint32_t bit = ((rec >> 6) & 0xFFF8u) + __umul24(kind == KIND_DIRECT ? idx : 0u, w);
+        if (!act || (LINEAR && kind == KIND_DELTA)) bit = 0;
         uint64_t val;
-        if (any_linear && kind == KIND_DELTA) {
-            val = cur_base + (uint64_t)idx * cur_aux;
+        if (WIDE) {
+            const uint64_t m = lds_bits64(wv.lds, bit, w ? w : 1u);
+            val = SIGNED ? zigzag(m) : m;
         } else {
-            // a packed field of a Direct run, or the one field a ShortRepeat run consists of
-            const uint32_t bit = act ? cur_bit + (kind == KIND_DIRECT ? idx * w : 0u) : 0u;  // (inactive lanes read inside the slice)
-            const uint64_t m = wide ? lds_bits64(wv.lds, bit, w ? w : 1u) : (uint64_t)lds_bits32(wv.lds, bit, w ? w : 1u);
-            val = wv.is_signed ? zigzag(m) : m;
+            const uint32_t m = lds_bits32(wv.lds, bit, w ? w : 1u);
+            // (a zigzag field of at most 32 bits: the sign fills the upper half)
+            const uint32_t sign = 0u - (m & 1u);
+            val = SIGNED ? ((uint64_t)sign << 32) | ((m >> 1) ^ sign) : (uint64_t)m;
         }
-        return val;
-    };
-    v[0] = slot(0);
-    v[1] = slot(1);
-    v[2] = slot(2);
-    v[3] = slot(3);
-    v[4] = slot(4);
-    v[5] = slot(5);
-    v[6] = slot(6);
-    v[7] = slot(7);
-    // registers -> LDS -> the layout of the stores.  Pairs (2 p, 2 p + 1) of lane i go to 16-byte
-    // slot 64 p + i (neighbouring lanes, neighbouring slots); lane i of step j wants the pair
+        if (LINEAR) {  // Delta without packed deltas: base + index * step
+            const uint64_t base = shfl64(my_base, (int)(k & 63u)), step = shfl64(my_aux, (int)(k & 63u));
+            if (kind == KIND_DELTA) val = base + (uint64_t)idx * step;
+        }
+        v[t] = val;
+    }
+    // registers -> LDS -> the layout of the stores.  Pairs (2 q, 2 q + 1) of lane i go to 16-byte
+    // slot 64 q + i (neighbouring lanes, neighbouring slots); lane i of step j wants the pair
     // 2 (i & 3) of lane 16 j + (i >> 2).
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // every read of the packed bytes is done
     u64x2 *tile = (u64x2 *)wv.lds;
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
+    for (int q = 0; q < 4; q++) {
         u64x2 pair;
-        pair.x = v[2 * p];
-        pair.y = v[2 * p + 1];
-        tile[64 * p + lane] = pair;
+        pair.x = v[2 * q];
+        pair.y = v[2 * q + 1];
+        tile[64 * q + lane] = pair;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    int64_t *wout = wv.out + wbase;
+    const bool full = lo_w == 0 && hi_w == WINDOW && wv.out_aligned;  // (wave-uniform)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const u64x2 pair = tile[64 * (lane & 3) + 16 * j + (lane >> 2)];
-        const uint64_t e0 = wbase + 128u * j + 2u * (uint32_t)lane;
-        store_pair(wv, e0, pair.x, pair.y, e0 >= lo && e0 < hi, e0 + 1 >= lo && e0 + 1 < hi);
+        const uint32_t p = 128u * j + 2u * (uint32_t)lane;
+        if (full) {
+            stream_store2(wout + p, pair.x, pair.y);
+        } else {
+            if (p - lo_w < hi_w - lo_w) stream_store1(wout + p, pair.x);
+            if (p + 1 - lo_w < hi_w - lo_w) stream_store1(wout + p + 1, pair.y);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the slice may be staged into again
+}
+
+// The runs rb, rb + 1, ... of the table that start before `own_end`, as decode_run_batch takes
+// them, when none of them carries a running sum or patches and their bytes fit the LDS slice;
+// MODE_VALUES only.  Returns false, with nothing written, for any other batch (decode_run_batch
+// takes it then); otherwise `next_beg` is the index after the last run's last value.
+template <class W>
+__device__ __forceinline__ bool decode_short_batch(const W &wv, const uint64_t *runs, uint32_t rb, uint32_t avail,
+                                                   const uint64_t batch_beg, const uint64_t own_end,
+                                                   uint32_t &nb, uint64_t &next_beg) {
+    const int lane = wv.lane;
+    const bool held = (uint32_t)lane < avail;
+    uint64_t desc = make_desc(0, KIND_SHORT_REPEAT, 0, 1, 0, 1);
+    if (held) desc = runs[rb + lane];
+    const uint32_t len = held ? desc_len(desc) : 0u;
+    const uint32_t incl = wave_scan_dpp(len);
+    const uint32_t rel = incl - len;
+    // (the batch's first run starts inside the window: own_end - batch_beg is 1..512.  Slots of the
+    // table past the window's runs may hold anything; lengths are 1..512 whatever the bits.)
+    const uint32_t room = (uint32_t)(own_end - batch_beg);
+    const bool mine = held && rel < room;
+    nb = (uint32_t)__builtin_popcountll(__ballot(mine));
+    if (nb == 0) {
+        next_beg = batch_beg;
+        return true;
+    }
+    const uint32_t kind = desc_kind(desc), w = desc_width(desc);
+    if (__ballot(mine && !(kind == KIND_SHORT_REPEAT || kind == KIND_DIRECT || (kind == KIND_DELTA && w == 0))))
+        return false;
+    const int last = (int)nb - 1;
+    const uint64_t batch_all = batch_beg + readlane32(incl, last);
+    const uint64_t batch_end = batch_all < wv.num_values ? batch_all : wv.num_values;
+    next_beg = batch_all;
+    if (batch_beg >= batch_end) return true;  // every run of the batch lies after the last wanted value
+    // the batch's last run, which alone may reach past the window
+    const uint64_t t_start = batch_beg + readlane32(rel, last);
+    const uint64_t t_pay = readlane64(desc_payload(desc), last);
+    const uint32_t t_len = readlane32(len, last), t_kind = readlane32(kind, last), t_w = readlane32(w, last);
+    const uint64_t wbase = own_end - WINDOW;
+    const uint64_t hi = own_end < batch_end ? own_end : batch_end;
+    // bytes of the window: from the first run's packed bytes to the last byte that the last run's
+    // values in front of `hi` take
+    const uint32_t t_count = hi > t_start ? ((hi - t_start) < t_len ? (uint32_t)(hi - t_start) : t_len) : 0u;
+    const uint64_t b0 = readlane64(desc_payload(desc), 0);
+    const uint64_t b1 = t_pay + (t_kind == KIND_DIRECT ? ((uint64_t)t_count * t_w + 7) >> 3
+                                                        : (t_kind == KIND_SHORT_REPEAT ? t_w >> 3 : 0u));
+    if (b1 < b0 || b1 - b0 + 15 > STAGE_BYTES) return false;
+    const bool any_linear = __ballot(mine && kind == KIND_DELTA) != 0;
+    const bool wide = __ballot(mine && kind != KIND_DELTA && w > 32) != 0;
+    uint64_t base = 0, aux = 0;
+    if (mine && kind == KIND_DELTA) {
+        // the header scan accepted this header: the parse cannot fail, and reads what it read
+        const uint64_t pos = desc_payload(desc) - desc_header_bytes(desc);
+        ParsedRun r;
+        r.base = 0;
+        r.aux = 0;
+        if (pos < wv.len && parse_run(load_window(wv.s, wv.len, pos), wv.s, wv.len, pos, wv.is_signed, r) == SEG_OK) {
+            base = r.base;
+            aux = r.aux;
+        }
+    }
+    {
+        const uint64_t origin = b1 > b0 ? stage_bytes(wv, b0, b1) : b0;
+        const uint32_t my_ws = mine ? rel + (uint32_t)(batch_beg - wbase) : 0xFFFFFFFFu;
+        const uint32_t my_rec = (my_ws & 511u) |
+                                ((((uint32_t)desc_payload(desc) - (uint32_t)origin) & 8191u) << 9) |
+                                (w << 22) | (kind << 29);
+        const uint32_t lo_w = (uint32_t)(batch_beg - wbase), hi_w = (uint32_t)(hi - wbase);
+        if (any_linear) {
+            if (wv.is_signed) expand_window_by_marks<true, true, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
+            else expand_window_by_marks<true, true, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
+        } else if (wide) {
+            if (wv.is_signed) expand_window_by_marks<true, false, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
+            else expand_window_by_marks<true, false, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
+        } else {
+            if (wv.is_signed) expand_window_by_marks<false, false, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
+            else expand_window_by_marks<false, false, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
+        }
+    }
+    // the windows behind: what the last run holds from own_end on; lane i takes values i, i + 64, ...
+    const uint64_t t_base = readlane64(base, last), t_step = readlane64(aux, last);
+    for (uint64_t wb = own_end; wb < batch_end; wb += WINDOW) {
+        const uint64_t we = (wb + WINDOW) < batch_end ? wb + WINDOW : batch_end;
+        const uint32_t first = (uint32_t)(wb - t_start), end = (uint32_t)(we - t_start);  // indices in the run
+        uint32_t bit0 = 0;  // bit in the slice of the run's packed field 0 (modulo 2^32)
+        if (t_kind != KIND_DELTA) {
+            const uint64_t f0 = t_kind == KIND_DIRECT ? ((uint64_t)first * t_w) >> 3 : 0u;
+            const uint64_t f1 = t_kind == KIND_DIRECT ? ((uint64_t)end * t_w + 7) >> 3 : t_w >> 3;
+            const uint64_t origin = stage_bytes(wv, t_pay + f0, t_pay + f1);
+            bit0 = (uint32_t)((t_pay - origin) << 3);
+        }
+        for (uint32_t idx = first + (uint32_t)lane; idx < end; idx += 64) {
+            uint64_t val = t_base + (uint64_t)idx * t_step;  // Delta without packed deltas
+            if (t_kind != KIND_DELTA) {
+                const uint64_t m = lds_bits64(wv.lds, bit0 + (t_kind == KIND_DIRECT ? idx * t_w : 0u), t_w);
+                val = wv.is_signed ? zigzag(m) : m;
+            }
+            stream_store1(wv.out + t_start + idx, val);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the slice may be staged into again
+    }
+    return true;
 }
 
 // The runs rb, rb + 1, ... of the table that start before `own_end` (the end of the wavefront's
@@ -1284,7 +1378,7 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
     me.aux = 0;
     const bool held = (uint32_t)lane < avail;
     if (held) me.desc = runs[rb + lane];
-    const uint32_t incl_all = wave_scan_u32(held ? desc_len(me.desc) : 0u, lane);
+    const uint32_t incl_all = wave_scan_dpp(held ? desc_len(me.desc) : 0u);
     const bool mine = held && batch_beg + (incl_all - desc_len(me.desc)) < own_end;
     nb = (uint32_t)__builtin_popcountll(__ballot(mine));
     if (nb == 0) return batch_beg;
@@ -1296,25 +1390,17 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
     const uint64_t batch_all = batch_beg + readlane32(incl_all, (int)nb - 1);
     uint64_t batch_end = batch_all < wv.num_values ? batch_all : wv.num_values;
     if (batch_beg >= batch_end) return batch_all;  // every run of the batch lies after the last wanted value
-    // no run of the batch carries a running sum or patches: expand_window_by_lane does the windows,
-    // and reads the value of a ShortRepeat run from the staged bytes like a packed field
-    const bool by_lane = W::BY_LANE && __ballot(mine && !(my_kind == KIND_SHORT_REPEAT || my_kind == KIND_DIRECT ||
-                                            (my_kind == KIND_DELTA && my_w == 0))) == 0;
-    bool have_repeats = !by_lane;
-    auto load_repeats = [&]() {
+    if (mine && my_kind == KIND_SHORT_REPEAT) {
         // the repeated value: width / 8 bytes, most significant first, right behind the header byte
         // (rle_v2.rs:283-301); the header scan has checked that they lie inside the stream
-        if (mine && my_kind == KIND_SHORT_REPEAT) {
-            const uint64_t pay = desc_payload(me.desc);
-            const uint8_t *p = wv.s + pay;
-            const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
-            if (my_w >= 8 && pay + (my_w >> 3) <= wv.len) {
-                const uint64_t v = global_bits((const uint32_t *)(p - sk), (uint64_t)sk * 8, my_w);
-                me.base = wv.is_signed ? zigzag(v) : v;
-            }
+        const uint64_t pay = desc_payload(me.desc);
+        const uint8_t *p = wv.s + pay;
+        const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
+        if (my_w >= 8 && pay + (my_w >> 3) <= wv.len) {
+            const uint64_t v = global_bits((const uint32_t *)(p - sk), (uint64_t)sk * 8, my_w);
+            me.base = wv.is_signed ? zigzag(v) : v;
         }
-    };
-    if (!by_lane) load_repeats();
+    }
     if (mine && my_kind != KIND_DIRECT && my_kind != KIND_SHORT_REPEAT) {
         // the header scan accepted this header: the parse cannot fail, and reads what it read
         const uint64_t pos = desc_payload(me.desc) - desc_header_bytes(me.desc);
@@ -1327,10 +1413,6 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
         }
     }
     uint64_t carry = 0;  // running value of a Delta run that continues into the next step
-    const bool any_linear = __ballot(mine && my_kind == KIND_DELTA) != 0;
-    const bool wide = __ballot(mine && my_kind != KIND_DELTA && my_w > 32) != 0;
-    const uint32_t my_kw = my_kind | (my_w << 2) | ((my_len - 1) << 9);
-    const uint32_t last_rel = readlane32(my_rel, (int)nb - 1);  // where the batch's last run starts
 
     for (uint64_t wbase = (batch_beg >> WINDOW_SHIFT) << WINDOW_SHIFT; wbase < batch_end;
          wbase += WINDOW) {
@@ -1342,12 +1424,7 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
         bool needs = false, scans = false;
         // (positions relative to the batch's first value fit 32 bits: 64 runs of at most 512)
         const uint32_t lo_rel = (uint32_t)(lo - batch_beg), hi_rel = (uint32_t)(hi - batch_beg);
-        if (by_lane && mine && my_kind == KIND_SHORT_REPEAT && my_rel < hi_rel && my_rel + my_len > lo_rel) {
-            // the repeated value's bytes are staged like a packed field (of which it is one)
-            needs = true;
-            need_b0 = desc_payload(me.desc);
-            need_b1 = need_b0 + (my_w >> 3);
-        } else if ((uint32_t)lane < nb && my_rel < hi_rel && my_rel + my_len > lo_rel &&
+        if ((uint32_t)lane < nb && my_rel < hi_rel && my_rel + my_len > lo_rel &&
             my_kind != KIND_SHORT_REPEAT && my_w != 0) {
             const uint32_t first = my_rel >= lo_rel ? 0u : lo_rel - my_rel;
             const uint32_t last = (my_rel + my_len) <= hi_rel ? my_len : hi_rel - my_rel;
@@ -1374,38 +1451,7 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
             }
         }
 
-        if (by_lane && W::MODE == MODE_VALUES && lo_rel >= last_rel && (use_lds || need_mask == 0)) {
-            // what is wanted of this window lies in the batch's last run (its tail, reaching over
-            // from the window before): lane i takes values lo + i, lo + i + 64, ... of it
-            const uint32_t kw = my_kind | (my_w << 2);
-            const uint32_t t_kw = readlane32(kw, (int)nb - 1);
-            const uint32_t t_bit = readlane32(((uint32_t)desc_payload(me.desc) - (uint32_t)lds_origin) << 3, (int)nb - 1);
-            const uint64_t t_base = readlane64(me.base, (int)nb - 1), t_aux = readlane64(me.aux, (int)nb - 1);
-            const uint32_t t_kind = t_kw & 3u, t_w = t_kw >> 2;
-            for (uint32_t r = lo_rel + (uint32_t)lane; r < hi_rel; r += 64) {
-                const uint32_t idx = r - last_rel;
-                uint64_t val = t_base + (uint64_t)idx * t_aux;  // Delta without packed deltas
-                if (t_kind != KIND_DELTA) {
-                    const uint64_t m = lds_bits64(wv.lds, t_bit + (t_kind == KIND_DIRECT ? idx * t_w : 0u), t_w);
-                    val = wv.is_signed ? zigzag(m) : m;
-                }
-                stream_store1(wv.out + batch_beg + r, val);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // the slice may be staged into again
-            continue;
-        }
-        if (by_lane && (use_lds || need_mask == 0)) {
-            const uint32_t my_bit = ((uint32_t)desc_payload(me.desc) - (uint32_t)lds_origin) << 3;
-            expand_window_by_lane(wv, wbase, lo, hi, batch_beg, my_rel, my_kw, my_bit, me.base, me.aux,
-                                  any_linear, wide);
-            continue;
-        }
         // ---- decode the window: 4 steps of 128 values -------------------------------------
-        if (!have_repeats) {  // (wave-uniform)
-            load_repeats();
-            have_repeats = true;
-        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint64_t e0 = wbase + 128u * j + 2u * lane;
@@ -1530,6 +1576,10 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
 // window g; bit 2 of *flags is raised when a PatchedBase run was met, whose patches are not part of
 // the sums.  MODE_OFFSETS: group_sums[g] holds the sum of all values before group g, and out[i]
 // receives the sum of the values before i.
+// SHORT: the variant for columns of short runs (many runs per window), compiled for fewer
+// wavefronts per SIMD and more registers each; only there does a batch of runs without running
+// sums take the lane-per-eight-values path (decode_short_batch), whose registers the variant for
+// long runs, which wants all eight wavefronts to saturate HBM, cannot afford.
 template <int MODE, bool SHORT>
 __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ runs,
@@ -1548,9 +1598,11 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
     }
     const uint32_t g = wg * VAL_WAVES + wave;
     if (g >= n_groups) return;  // whole wavefront leaves; no workgroup barrier is used below
-    WaveOf<MODE, SHORT> wv;
+    __shared__ uint32_t marks[VAL_WAVES][WINDOW / 32];
+    WaveOf<MODE> wv;
     wv.s = s;
     wv.lds = stage[wave];
+    wv.marks = marks[wave];
     wv.out = out;
     wv.num_values = num_values;
     wv.len = len;
@@ -1580,7 +1632,11 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
         if (r0 > n_runs) r0 = n_runs;
         for (uint32_t rb = (uint32_t)r0; rb < n_runs && beg < own_end; rb += 64) {
             uint32_t nb;
-            beg = decode_run_batch(wv, runs, rb, n_runs - rb, beg, own_end, nb);
+            uint64_t next_beg;
+            if (SHORT && MODE == MODE_VALUES && decode_short_batch(wv, runs, rb, n_runs - rb, beg, own_end, nb, next_beg))
+                beg = next_beg;
+            else
+                beg = decode_run_batch(wv, runs, rb, n_runs - rb, beg, own_end, nb);
             if (nb < 64) break;
         }
     }
@@ -1634,6 +1690,7 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel
     WaveOf<MODE_VALUES> wv;
     wv.s = s;
     wv.lds = stage[wave];
+    wv.marks = nullptr;  // (only the variant for short runs uses them)
     wv.out = out;
     wv.num_values = num_values;
     wv.len = len;
