@@ -1244,11 +1244,12 @@ __device__ __forceinline__ void expand_window_by_marks(const W &wv, uint64_t wba
     for (int j = 0; j < 4; j++) {
         const u64x2 pair = tile[64 * (lane & 3) + 16 * j + (lane >> 2)];
         const uint32_t p = 128u * j + 2u * (uint32_t)lane;
-        if (full) {
+        const bool a0 = p - lo_w < hi_w - lo_w, a1 = p + 1 - lo_w < hi_w - lo_w;
+        if (full || (a0 && a1 && wv.out_aligned)) {
             stream_store2(wout + p, pair.x, pair.y);
         } else {
-            if (p - lo_w < hi_w - lo_w) stream_store1(wout + p, pair.x);
-            if (p + 1 - lo_w < hi_w - lo_w) stream_store1(wout + p + 1, pair.y);
+            if (a0) stream_store1(wout + p, pair.x);
+            if (a1) stream_store1(wout + p + 1, pair.y);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
