@@ -50,7 +50,11 @@ DEFAULT_ROWS = {"strings_w6": 250_000_000, "boolean_mix": 4_000_000_000, "mixed_
                 "mixed_short_runs_sparse": 500_000_000}
 
 
-EXTRA_WORKLOADS = ["delta_w10", "delta_w16", "mixed_short_runs", "boolean_mix", "strings_w6"]
+EXTRA_WORKLOADS = ["delta_w10", "delta_w16", "mixed_short_runs", "boolean_mix", "strings_w6", "strings_file"]
+# strings_file: the string configuration as an ORC file, end to end (read + H2D + decode + D2H of
+# the offsets); stripes of 2 000 000 strings, about 64 MB of DATA each
+FILE_STRIPES, FILE_STRINGS_PER_STRIPE = 32, 2_000_000
+FILE_CONTEXTS = int(os.environ.get("ORCD_BENCH_FILE_CONTEXTS", "4"))
 
 
 def spawn_ranks(args):
@@ -78,7 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=None,
                     help="values per GPU per step (default 1e9; 2.5e8 strings for strings_w6)")
-    ap.add_argument("--workload", default="direct_w17", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="direct_w17", choices=sorted(WORKLOADS) + ["strings_file"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the `workloads` object (the other configurations, shorter runs)")
@@ -130,9 +134,11 @@ def main():
             sub.cpu_seconds, sub.end_to_end = min(args.cpu_seconds, 4.0), False
             torch.cuda.empty_cache()
             r = run_workload(sub, wl, rank, world, local_rank, dist, torch, np)
-            keep = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "roofline",
+            keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "roofline",
                                       "phases_ms", "decoded_frac_of_hbm_peak", "cpu_baseline",
-                                      "zero_copy_variant") if k in r}
+                                      "zero_copy_variant", "decoded_GBps") if k in r}
+            if wl != "strings_file":
+                keep.pop("metric", None)  # (the headline's metric)
             keep["workload"] = r["config"]["workload"]
             result["workloads"][wl] = keep
     if rank == 0:
@@ -145,6 +151,10 @@ def main():
 
 
 def run_workload(args, workload, rank, world, local_rank, dist, torch, np):
+    if workload == "strings_file":
+        args = argparse.Namespace(**vars(args))
+        args.workload = workload
+        return bench_strings_file(args, rank, world, local_rank, dist, torch, np)
     gen_name, gen_kw, signed, desc = WORKLOADS[workload]
     args = argparse.Namespace(**vars(args))
     args.workload = workload
@@ -401,6 +411,80 @@ def bench_strings(args, rank, world, local_rank, dist, desc, torch, np):
             "kind": "port", "sample": "first %d strings (%.1f MB of DATA) of the same column, single "
                                       "thread, %.1f s" % (n_s, nbytes / 1e6, dt)}
     return result
+
+
+def bench_strings_file(args, rank, world, local_rank, dist, torch, np):
+    """One step = one pass over this rank's ORC file of direct-encoded strings, from the file's
+    bytes (page cache) to the decoded column: stripe reads, host-to-device copies, LENGTH -> offsets,
+    DATA -> copied and UTF-8-checked bytes on the GPU, offsets copied back to the host.  The stripes
+    alternate between FILE_CONTEXTS contexts with a host thread each, so that one stripe's read
+    and copy overlap another's decode.  This line measures the feed (PCIe, page cache), not a
+    kernel: it carries no roofline."""
+    import shutil
+    import tempfile
+    from bench_util import orc_write
+    from orc_format_amd import Context, read, shard
+
+    n_stripes = FILE_STRIPES if args.rows is None else max(1, args.rows // FILE_STRINGS_PER_STRIPE)
+    tmp = tempfile.mkdtemp(prefix="orcd_bench_")
+    try:
+        path = os.path.join(tmp, "strings_%d.orc" % rank)
+        templates, size = orc_write.write_string_file(path, n_stripes, FILE_STRINGS_PER_STRIPE,
+                                                      seed=46 + 1000 * rank)
+        md = read.read_metadata(path)
+        contexts = [Context(local_rank) for _ in range(FILE_CONTEXTS)]
+        want = [np.concatenate([[0], np.cumsum(t[0])]).astype(np.int64) for t in templates]
+        decoded = [0]
+
+        def on_stripe(context, stripe, cols):
+            col = cols[0]
+            offsets = context.copy_to_host(col.offsets_ptr, col.num_slots + 1, np.int64)
+            decoded[0] += col.num_bytes + offsets.nbytes
+            keep = (stripe, offsets, col.num_bytes)
+            col.free()
+            return keep
+
+        def one_pass():
+            return shard.decode_file_shard(contexts[0], md, 0, 1, columns=[1], row_aligned=False,
+                                           check_utf8=True, extra_contexts=contexts[1:], device=True,
+                                           on_stripe=on_stripe)
+
+        def barrier():
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+
+        for _ in range(min(args.warmup, 1)):
+            one_pass()
+        steps = max(1, min(args.steps, 3))
+        decoded[0] = 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = one_pass()
+        barrier()
+        elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist, device=REDUCE_DEVICE)
+        for _, _, (stripe, offsets, num_bytes) in res:
+            w = want[stripe % len(want)]
+            if num_bytes != int(w[-1]) or not np.array_equal(offsets, w):
+                raise SystemExit("bench.py: offsets of stripe %d differ from the lengths written" % stripe)
+        for c in contexts:
+            c.close()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {
+        "metric": "end-to-end GB/s of ORC file (read + H2D + decode + D2H of offsets)",
+        "value": round(size * steps * world / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": world,
+        "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": round(elapsed / steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "decoded_GBps": round(decoded[0] * world / elapsed / 1e9, 2),
+        "config": {"workload": "strings_file: uncompressed ORC file of %d stripes x %d strings, lengths "
+                               "U[8,56] as RLE v2 Direct width 6, ASCII DATA (seed 46), %d bytes per GPU; "
+                               "%d contexts per GPU" % (n_stripes, FILE_STRINGS_PER_STRIPE, size, FILE_CONTEXTS),
+                   "file_bytes_per_gpu": size, "stripes": n_stripes,
+                   "parallelism": "stripe-sharded x%d" % world},
+    }
 
 
 def bench_boolean(args, rank, world, local_rank, dist, desc, torch, np):

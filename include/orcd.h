@@ -89,6 +89,12 @@ int orcd_ctx_synchronize(orcd_ctx *ctx);
  * temporaries of orcd_decode_column / orcd_decode_stripe) back to the runtime; waits for the
  * context's queued work first.  Nothing else changes: the next call allocates afresh. */
 int orcd_ctx_release_cached(orcd_ctx *ctx);
+/* Copies `bytes` bytes from device memory -- typically one array of an orcd_column_data that was
+ * asked for with ORCD_OUT_DEVICE, such as the offsets of a string column whose bytes stay on the
+ * GPU -- to host memory, on the context's stream, and waits for it.  (The reference keeps
+ * everything in host Vecs, src/read/decode/variable_length.rs:5-28; this is the piece a caller
+ * needs that keeps the large arrays on the GPU.) */
+int orcd_ctx_copy_to_host(orcd_ctx *ctx, void *dst, const void *src_device, size_t bytes);
 /* Duration in milliseconds of the GPU work of the most recent decode call on this context,
  * measured with HIP events on the context's stream (waits for that work).  Negative on error. */
 float orcd_ctx_last_elapsed_ms(orcd_ctx *ctx);

@@ -44,6 +44,31 @@ def _column_dict(cd):
     return out
 
 
+class DeviceColumn:
+    """One decoded column of one stripe whose arrays stayed on the GPU (orcd_column_data with
+    on_device set): raw device addresses and counts.  The memory goes back to the context that
+    made it on free() -- call it (or drop the object) before that context is closed."""
+
+    def __init__(self, lib, cd):
+        self._lib = lib
+        self._cd = N.ColumnData.from_buffer_copy(cd)
+        self.type_kind = cd.type_kind
+        self.num_rows, self.num_values, self.num_slots = cd.num_rows, cd.num_values, cd.num_slots
+        self.validity_ptr, self.values_ptr, self.value_size = cd.validity or 0, cd.values or 0, cd.value_size
+        self.offsets_ptr, self.bytes_ptr, self.num_bytes = cd.offsets or 0, cd.bytes or 0, cd.num_bytes
+
+    def free(self):
+        if self._cd is not None:
+            self._lib.orcd_column_data_free(C.byref(self._cd))
+            self._cd = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Context:
     def __init__(self, device=0):
         self._lib = N.lib()
@@ -79,6 +104,12 @@ class Context:
 
     def synchronize(self):
         check(self._lib.orcd_ctx_synchronize(self._h), self._h)
+
+    def copy_to_host(self, device_ptr, count, dtype):
+        """`count` items of `dtype` from a device address (an array of a DeviceColumn) as numpy."""
+        out = np.empty(count, dtype=dtype)
+        check(self._lib.orcd_ctx_copy_to_host(self._h, out.ctypes.data, device_ptr, out.nbytes), self._h)
+        return out
 
     def release_cached(self):
         """Returns the device memory kept for the next column calls to the runtime."""
@@ -219,14 +250,19 @@ class Context:
         finally:
             self._lib.orcd_column_data_free(C.byref(cd))
 
-    def decode_stripe(self, metadata, stripe, footer, columns, check_utf8=True, row_aligned=False):
-        """Several columns of one stripe through orcd_decode_stripe (host results): a list of the
-        dicts decode_column returns."""
+    def decode_stripe(self, metadata, stripe, footer, columns, check_utf8=True, row_aligned=False,
+                      device=False):
+        """Several columns of one stripe through orcd_decode_stripe: a list of the dicts
+        decode_column returns (host results), or with device=True of DeviceColumn objects whose
+        arrays stay on the GPU."""
         cols = (C.c_uint32 * len(columns))(*columns)
         cds = (N.ColumnData * len(columns))()
-        flags = (N.CHECK_UTF8 if check_utf8 else 0) | (N.ROW_ALIGNED if row_aligned else 0)
+        flags = (N.CHECK_UTF8 if check_utf8 else 0) | (N.ROW_ALIGNED if row_aligned else 0) | \
+            (N.OUT_DEVICE if device else 0)
         check(self._lib.orcd_decode_stripe(self._h, metadata._h, stripe, footer._h, cols, len(columns),
                                            flags, cds), self._h)
+        if device:
+            return [DeviceColumn(self._lib, cd) for cd in cds]
         try:
             return [_column_dict(cd) for cd in cds]
         finally:

@@ -866,6 +866,12 @@ int orcd_ctx_release_cached(orcd_ctx *c) try {
     return ORCD_OK;
 } ORCD_CATCH
 
+int orcd_ctx_copy_to_host(orcd_ctx *c, void *dst, const void *src_device, size_t bytes) try {
+    if (!c || (bytes && (!dst || !src_device))) return ORCD_INVALID_ARGUMENT;
+    DeviceGuard g(c->device);
+    return copy_out(c, dst, src_device, bytes);
+} ORCD_CATCH
+
 int orcd_ctx_synchronize(orcd_ctx *c) try {
     if (!c) return ORCD_INVALID_ARGUMENT;
     DeviceGuard g(c->device);

@@ -58,7 +58,7 @@ def sum_over_ranks(value, dist=None, device=None):
 
 
 def decode_file_shard(ctx, metadata, rank, world_size, columns=None, row_aligned=True,
-                      check_utf8=True, extra_contexts=()):
+                      check_utf8=True, extra_contexts=(), device=False, on_stripe=None):
     """The stripes of an open file that fall to `rank`, decoded on that rank's context (one
     orcd_decode_stripe call per stripe).  Returns a list of (stripe index, first row of the stripe
     in the file, [column dicts as Context.decode_stripe returns them]); the ranks' lists together
@@ -70,7 +70,12 @@ def decode_file_shard(ctx, metadata, rank, world_size, columns=None, row_aligned
     (it has no lock: its buffers, pinned words and stamps are per call), so every context gets one
     host thread of its own, which decodes that context's share of the stripes -- every
     len(contexts)-th of the rank's -- one after the other; one stripe's read and copy then overlap
-    another's decode on a different context."""
+    another's decode on a different context.
+
+    device: the columns stay on the GPU (context.DeviceColumn objects instead of dicts).
+    on_stripe(context, stripe, columns): called by the decoding thread after each stripe, e.g. to
+    copy the offsets of a string column to the host, or to free the columns when only the rate is
+    wanted; what it returns takes the columns' place in the result."""
     from . import read
     if columns is None:
         columns = list(range(1, len(metadata.types)))
@@ -80,9 +85,11 @@ def decode_file_shard(ctx, metadata, rank, world_size, columns=None, row_aligned
 
     def one(context, stripe):
         footer = read.read_stripe_footer(metadata, stripe)
-        return (stripe, first_rows[stripe],
-                context.decode_stripe(metadata, stripe, footer, columns, check_utf8=check_utf8,
-                                      row_aligned=row_aligned))
+        cols = context.decode_stripe(metadata, stripe, footer, columns, check_utf8=check_utf8,
+                                     row_aligned=row_aligned, device=device)
+        if on_stripe is not None:
+            cols = on_stripe(context, stripe, cols)
+        return (stripe, first_rows[stripe], cols)
     if len(contexts) == 1:
         return [one(ctx, stripe) for stripe in mine]
     import threading
