@@ -631,6 +631,195 @@ __global__ __launch_bounds__(64) void bool_count_sum_kernel(unsigned long long *
     if (threadIdx.x == 0) set_bits[0] = v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Entry points for a stream that came without any.
+//
+// Where the control bytes lie follows only from the start of the stream, one run after the other
+// (boolean_rle.rs:40-62) -- but a run is at most 129 stream bytes (a control byte and 128
+// literals), so the first control byte at or after any position p lies at one of p .. p + 128.
+// The stream is cut into segments of BC_SEG bytes; for segment k and each of those 129 candidate
+// offsets c, byte_rle_exits_kernel walks the chain from k * BC_SEG + c to where it first leaves
+// the segment: exit[k][c], again 0..128, relative to the next segment.  The true offset of segment
+// k + 1 is exit[k][true offset of segment k], and the true offset of segment 0 is 0: a chain of
+// table look-ups, which is a prefix "sum" under composition of 129-entry tables and is taken in
+// the usual two sweeps, BC_FAN tables at a time (compose_up builds the table of a group of
+// tables, compose_down walks a group from its known start).  Nothing here is a guess.
+// ---------------------------------------------------------------------------------------------
+
+constexpr uint32_t BC_CAND = 129;
+constexpr uint32_t BC_STAGE = BC_SEG + 160;  // a segment, the 128 bytes a walk may run past it, the load skew
+
+// tab[k * BC_PITCH + c], k < n_tab: every segment but the last, whose exits nobody needs.
+// A walk is a chain of dependent LDS reads, so the bytes are first turned into hop lengths in
+// place (2 for a run, 1 + n for n literals) and a second array takes the length of two hops in a
+// row (less 4, to fit a byte): a walk then moves two runs per step while that keeps it inside the
+// segment.
+__global__ __launch_bounds__(256) void byte_rle_exits_kernel(const uint8_t *__restrict__ s, uint64_t len,
+                                                             uint32_t n_tab, uint8_t *__restrict__ tab) {
+    __shared__ __attribute__((aligned(16))) uint8_t hop_all[4][BC_STAGE];
+    __shared__ __attribute__((aligned(16))) uint8_t hop2_all[4][BC_SEG + 32];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * 4 + wave;
+    if (k >= n_tab) return;  // whole wavefront; no workgroup barrier below
+    uint8_t *hop = hop_all[wave], *hop2 = hop2_all[wave];
+    const uint64_t base = (uint64_t)k * BC_SEG;
+    // whole aligned 16-byte chunks from the one that holds byte `base` on; a chunk that starts
+    // at or after the end of the stream is not loaded (its bytes read as zero: never on the chain
+    // of a stream that is in order, and harmless on any other)
+    const uint32_t skew = (uint32_t)((uintptr_t)(s + base) & 15);
+    const uint8_t *src = s + base - skew;
+    uint4 loaded[3];  // (all loads in flight before the first is used)
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint32_t c = lane + 64u * r;
+        loaded[r] = make_uint4(0, 0, 0, 0);
+        if (c < BC_STAGE / 16 && base + 16ull * c < len + skew) loaded[r] = ((const uint4 *)src)[c];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint32_t c = lane + 64u * r;
+        if (c >= BC_STAGE / 16) break;
+        const uint4 v = loaded[r];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t h = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t ctl = (w[q] >> (8 * e)) & 255u;
+                h |= (ctl < 128 ? 2u : 257u - ctl) << (8 * e);
+            }
+            w[q] = h;
+        }
+        ((uint4 *)hop)[c] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t limit = skew + BC_SEG;  // (at most 15 + 2048: hop2 has room for it)
+    for (uint32_t p4 = 4 * lane; p4 < limit; p4 += 256) {
+        const uint32_t h = *(const uint32_t *)(hop + p4);
+        uint32_t two = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t h1 = (h >> (8 * e)) & 255u;
+            two |= (h1 + hop[p4 + e + h1] - 4u) << (8 * e);
+        }
+        *(uint32_t *)(hop2 + p4) = two;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // three walks per lane: candidates lane, lane + 64 and (lane 0 only) 128
+    uint32_t p0 = skew + lane, p1 = skew + lane + 64, p2 = lane == 0 ? skew + 128 : limit;
+    auto step = [&](uint32_t &p) {
+        if (p < limit) {
+            const uint32_t one = hop[p], two = hop2[p] + 4u;
+            p += p + two < limit ? two : one;
+        }
+    };
+    while (__ballot(p0 < limit || p1 < limit || p2 < limit) != 0) {
+        step(p0);
+        step(p1);
+        step(p2);
+    }
+    uint8_t *row = tab + (uint64_t)k * BC_PITCH;
+    row[lane] = (uint8_t)(p0 - limit);
+    row[lane + 64] = (uint8_t)(p1 - limit);
+    if (lane == 0) row[128] = (uint8_t)(p2 - limit);
+}
+
+// out[o] = in[o * BC_FAN + BC_FAN - 1] o ... o in[o * BC_FAN]: a workgroup per group, which brings
+// the group's tables into LDS, then a thread per candidate walks them.
+__global__ __launch_bounds__(256) void byte_rle_compose_up_kernel(const uint8_t *__restrict__ in, uint32_t n_in,
+                                                                  uint8_t *__restrict__ out, uint32_t n_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t tabs[BC_FAN * BC_PITCH];
+    const uint64_t o = blockIdx.x;
+    const uint64_t first = o * BC_FAN;
+    const uint32_t m = (uint32_t)(n_in - first < BC_FAN ? n_in - first : BC_FAN);
+    const uint32_t *src = (const uint32_t *)(in + first * BC_PITCH);  // (BC_PITCH is a multiple of 4)
+    for (uint32_t i = threadIdx.x; i < m * (BC_PITCH / 4); i += 256) ((uint32_t *)tabs)[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x >= BC_CAND) return;
+    uint32_t x = threadIdx.x;
+    for (uint32_t i = 0; i < m; i++) x = tabs[i * BC_PITCH + x];
+    out[o * BC_PITCH + threadIdx.x] = (uint8_t)x;
+}
+
+// A wavefront per group of BC_FAN tables: from the group's true offset (start_in[o]; null: 0, the
+// one group at the top) to the true offset of each of its members: start_out[idx] (nullable), and
+// at the level of the segments themselves entries[idx] = idx * BC_SEG + offset, with entries[n]
+// from the last table's exit.  The tables come into LDS, lane 0 walks them, all lanes write.
+__global__ __launch_bounds__(64) void byte_rle_compose_down_kernel(const uint8_t *__restrict__ tab, uint32_t n,
+                                                                   const uint8_t *__restrict__ start_in,
+                                                                   uint8_t *__restrict__ start_out,
+                                                                   uint64_t *__restrict__ entries, uint64_t len) {
+    __shared__ __attribute__((aligned(16))) uint8_t tabs[BC_FAN * BC_PITCH];
+    __shared__ uint8_t offs[BC_FAN + 1];
+    const uint64_t o = blockIdx.x;
+    const uint64_t first = o * BC_FAN;
+    const uint32_t m = (uint32_t)(n - first < BC_FAN ? n - first : BC_FAN);
+    const uint32_t *src = (const uint32_t *)(tab + first * BC_PITCH);
+    for (uint32_t i = threadIdx.x; i < m * (BC_PITCH / 4); i += 64) ((uint32_t *)tabs)[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t x = start_in ? start_in[o] : 0u;
+        for (uint32_t i = 0; i < m; i++) {
+            offs[i] = (uint8_t)x;
+            x = tabs[i * BC_PITCH + x];
+        }
+        offs[m] = (uint8_t)x;
+    }
+    __syncthreads();
+    const uint32_t i = threadIdx.x;
+    if (i < m) {
+        if (start_out) start_out[first + i] = offs[i];
+        if (entries) {
+            const uint64_t e = (first + i) * BC_SEG + offs[i];
+            entries[first + i] = e < len ? e : len;
+        }
+    }
+    if (entries && i == 0 && first + m == n) {
+        const uint64_t e = (uint64_t)n * BC_SEG + offs[m];
+        entries[n] = e < len ? e : len;
+    }
+}
+
+size_t byte_rle_compose_bytes(uint64_t len, uint32_t *n_entries) {
+    const uint64_t k = (len + BC_SEG - 1) / BC_SEG;
+    *n_entries = (uint32_t)k;
+    size_t total = 0;
+    for (uint64_t n = k - 1; n > 0; n = n > BC_FAN ? (n + BC_FAN - 1) / BC_FAN : 0)
+        total += (size_t)((n * BC_PITCH + n + 255) / 256 * 256 + 256);  // a level's tables and offsets
+    return total;
+}
+
+hipError_t launch_byte_rle_compose_entries(hipStream_t st, const uint8_t *stream, uint64_t len, uint8_t *work,
+                                           uint64_t *entries) {
+    const uint64_t k = (len + BC_SEG - 1) / BC_SEG;
+    if (k < 2) return hipErrorInvalidValue;
+    // the levels: tables of n[l] elements at tab[l], their true offsets at off[l]
+    uint32_t n[8];
+    uint8_t *tab[8], *off[8];
+    int levels = 0;
+    uint8_t *p = work;
+    for (uint64_t m = k - 1; m > 0 && levels < 8; m = m > BC_FAN ? (m + BC_FAN - 1) / BC_FAN : 0) {
+        n[levels] = (uint32_t)m;
+        tab[levels] = p;
+        off[levels] = p + (size_t)m * BC_PITCH;
+        p += (size_t)((m * BC_PITCH + m + 255) / 256 * 256 + 256);
+        levels++;
+    }
+    byte_rle_exits_kernel<<<(n[0] + 3) / 4, 256, 0, st>>>(stream, len, n[0], tab[0]);
+    for (int l = 1; l < levels; l++)
+        byte_rle_compose_up_kernel<<<n[l], 256, 0, st>>>(tab[l - 1], n[l - 1], tab[l], n[l]);
+    for (int l = levels - 1; l >= 0; l--) {
+        const uint64_t groups = ((uint64_t)n[l] + BC_FAN - 1) / BC_FAN;
+        byte_rle_compose_down_kernel<<<(uint32_t)groups, 64, 0, st>>>(
+            tab[l], n[l], l + 1 < levels ? off[l + 1] : nullptr, l > 0 ? off[l] : nullptr,
+            l == 0 ? entries : nullptr, len);
+    }
+    return hipGetLastError();
+}
+
 constexpr uint64_t BR_MAX_BLOCKS = 256 * 16;  // workgroups of the expansion: 16 per CU
 // The boolean expansion: 256 per CU, i.e. a wavefront takes about two tiles of the largest columns
 // (measured on 4*10^9 values: 1.05 ms with 16 per CU, 0.98 with 128, 0.945 with 256, 0.953 with a

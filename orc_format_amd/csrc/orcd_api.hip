@@ -52,6 +52,7 @@ enum Slot {
     SLOT_TMP,
     SLOT_STAGED_RUNS,
     SLOT_SPEC_FLAG,    // the word a speculative launch raises when its guess about the stream is wrong
+    SLOT_COMPOSE,      // exit tables of a byte-RLE stream without entry points
     N_SLOTS
 };
 
@@ -509,6 +510,7 @@ int guess_entry_points(orcd_ctx *c, const uint8_t *d_stream, size_t len, int is_
     ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &d_tmp));
     uint64_t *d_word = (uint64_t *)d_tmp;
     uint64_t p = 0;
+    int short_rounds = 0;
     entries.clear();
     entries.push_back(0);
     for (int round = 0; round < GUESS_MAX_ROUNDS && p < len; round++) {
@@ -528,7 +530,10 @@ int guess_entry_points(orcd_ctx *c, const uint8_t *d_stream, size_t len, int is_
         if (p != entries.back()) entries.push_back(p);
         for (uint64_t k = ENTRY_RUNS; k < good; k += ENTRY_RUNS) entries.push_back(p + k * stride);
         p += good * stride;
-        if (good < ENTRY_RUNS && round >= 8) break;  // no long stretches here: stop paying a round per few runs
+        // no long stretches here: stop paying a round per few runs (what is left is walked by
+        // the speculative entries of rlev2_table, or serially)
+        short_rounds = good < ENTRY_RUNS ? short_rounds + 1 : 0;
+        if (short_rounds >= 2) break;
     }
     if (p < len && p != entries.back()) entries.push_back(p);  // the rest: one serial segment
     return ORCD_OK;
@@ -549,11 +554,22 @@ uint32_t pick_staged_cap(uint64_t len, uint32_t n_seg) {
 // Builds the run table of one RLE v2 stream that is already on the device.  d_seg_ends (nullable):
 // the end of every segment, for slices of a larger buffer decoded as one stream; seg_table
 // (nullable) receives the segment prefix sums for the caller's own checks.
+// Spacing of the speculative entry points of an irregular stream (rlev2_resync_kernel): as close
+// as the wavefront-per-segment counting pass allows, and never so close that a walk that started
+// off the chain has too little room to find it.
+constexpr uint64_t RESYNC_MIN_SPACING = 4096;
+constexpr uint64_t RESYNC_MIN_BYTES = 4 * RESYNC_MIN_SPACING;
+
+int rlev2_table_with(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
+                     const uint64_t *d_entries, size_t n_entries, int is_signed, Rlev2Table *t,
+                     bool full_table, const uint64_t *d_seg_ends, SegTable *seg_table);
+
 int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
                 const uint64_t *d_entries, size_t n_entries, int is_signed, Rlev2Table *t,
                 bool full_table = false, const uint64_t *d_seg_ends = nullptr,
                 SegTable *seg_table = nullptr) {
     if (n_entries > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
+    const bool no_entries = n_entries == 0;
     std::vector<uint64_t> guessed;
     if (n_entries == 0 && len >= GUESS_MIN_BYTES) {
         ORCD_TRY(guess_entry_points(c, d_stream, len, is_signed, guessed));
@@ -564,6 +580,33 @@ int rlev2_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
             n_entries = guessed.size();
         }
     }
+    // Not regular (what is left for one serial walk is long): speculative entry points, which the
+    // counting pass verifies; if they do not hold, the stream is walked as one segment after all,
+    // which also is what tells a stream that is out of spec from a guess that was off.
+    const uint64_t serial_tail = len - (guessed.empty() ? 0 : guessed.back());
+    if (no_entries && !d_seg_ends && serial_tail >= RESYNC_MIN_BYTES && serial_tail >= len / 2) {
+        uint64_t spacing = (len + COOP_MAX_SEGMENTS - 1) / COOP_MAX_SEGMENTS;
+        spacing = std::max<uint64_t>(RESYNC_MIN_SPACING, (spacing + 4095) / 4096 * 4096);
+        const uint64_t k = (len + spacing - 1) / spacing;
+        void *d;
+        ORCD_TRY(ensure(c, SLOT_IN_ENTRIES, k * sizeof(uint64_t), &d));
+        HIP_TRY(c, launch_rlev2_resync(c->stream, d_stream, len, is_signed, spacing, (uint32_t)k, (uint64_t *)d));
+        const int rc = rlev2_table_with(c, d_stream, len, num_values, (const uint64_t *)d, k, is_signed, t,
+                                        full_table, nullptr, seg_table);
+        if (rc != ORCD_OUT_OF_SPEC) return rc;
+        if (n_entries) {  // back to the entries of the regular part
+            const void *g;
+            ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, guessed.data(), guessed.size() * sizeof(uint64_t), false, &g));
+            d_entries = (const uint64_t *)g;
+        }
+    }
+    return rlev2_table_with(c, d_stream, len, num_values, d_entries, n_entries, is_signed, t, full_table,
+                            d_seg_ends, seg_table);
+}
+
+int rlev2_table_with(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
+                     const uint64_t *d_entries, size_t n_entries, int is_signed, Rlev2Table *t,
+                     bool full_table, const uint64_t *d_seg_ends, SegTable *seg_table) {
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
     const uint64_t *seg_ends = n_entries ? d_seg_ends : nullptr;
@@ -686,6 +729,8 @@ int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_va
     return ORCD_OK;
 }
 
+constexpr size_t BYTE_RLE_COMPOSE_MIN = 8 * BC_SEG;
+
 struct ByteRleTable {
     const ByteRun *runs;
     const uint32_t *win_first;
@@ -701,6 +746,17 @@ int byte_rle_table(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_
                    const uint64_t *d_seg_ends = nullptr, SegTable *seg_table = nullptr,
                    bool whole_stream = false, uint64_t *total_bytes = nullptr) {
     if (n_entries > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
+    // a long stream without entry points: they are computed (exactly) in front of the scan
+    if (n_entries == 0 && !d_seg_ends && len >= BYTE_RLE_COMPOSE_MIN && len / BC_SEG < 0xFFFFFFF0ull) {
+        uint32_t k = 0;
+        const size_t work_bytes = byte_rle_compose_bytes(len, &k);
+        void *work, *ent;
+        ORCD_TRY(ensure(c, SLOT_COMPOSE, work_bytes, &work));
+        ORCD_TRY(ensure(c, SLOT_IN_ENTRIES, (size_t)k * sizeof(uint64_t), &ent));
+        HIP_TRY(c, launch_byte_rle_compose_entries(c->stream, d_stream, len, (uint8_t *)work, (uint64_t *)ent));
+        d_entries = (const uint64_t *)ent;
+        n_entries = k;
+    }
     const uint32_t n_seg = segments_for(n_entries);
     const uint64_t *entries = n_entries ? d_entries : nullptr;
     const uint64_t *seg_ends = n_entries ? d_seg_ends : nullptr;

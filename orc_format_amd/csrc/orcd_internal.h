@@ -166,6 +166,10 @@ struct Rlev2Table {
     uint64_t num_values;
     int is_signed;
 };
+// Speculative entry points every `spacing` bytes for an irregular stream without any (see
+// rlev2_resync_kernel): entries[0 .. n_entries), to be verified by the counting pass.
+hipError_t launch_rlev2_resync(hipStream_t st, const uint8_t *stream, uint64_t len, int is_signed,
+                               uint64_t spacing, uint32_t n_entries, uint64_t *entries);
 hipError_t launch_rlev2_values(hipStream_t st, const Rlev2Table &t, int64_t *out);
 // Value expansion without a header scan, for the column whose every window of 512 values is one
 // Direct run of 512 values with equally many equal-sized runs between two entry points (see
@@ -185,6 +189,14 @@ hipError_t launch_rlev2_group_sums(hipStream_t st, const Rlev2Table &t, uint64_t
 hipError_t launch_rlev2_offsets(hipStream_t st, const Rlev2Table &t, const uint64_t *group_prefix,
                                 int64_t *offsets);
 
+// Entry points of a byte-RLE stream that came without any: entries[k], k < n_entries =
+// ceil(len / BC_SEG), is the first control byte at or after k * BC_SEG (len where there is none),
+// computed exactly (see byte_rle_exits_kernel).  `work`: byte_rle_compose_bytes(len) bytes of
+// device memory.  len must be more than BC_SEG.
+constexpr uint32_t BC_SEG = 2048, BC_PITCH = 132, BC_FAN = 64;
+size_t byte_rle_compose_bytes(uint64_t len, uint32_t *n_entries);
+hipError_t launch_byte_rle_compose_entries(hipStream_t st, const uint8_t *stream, uint64_t len, uint8_t *work,
+                                           uint64_t *entries);
 // (staged, staged_up_to: as for the RLE v2 passes; a staged word is the run's ByteRun::src)
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                                  const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,

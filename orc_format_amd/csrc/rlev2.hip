@@ -516,6 +516,54 @@ __global__ __launch_bounds__(256) void rlev2_coop_count_kernel(
     }
 }
 
+// Entry points for a stream of short runs that came without any and is not regular: entry k is a
+// guess at the first header at or after k * spacing.  One wavefront per entry walks 64 header
+// chains at once, lane l from (k - 1) * spacing + l, one segment in front of where the answer is
+// wanted.  Most of those offsets are no headers, and a walk that starts off the chain parses
+// garbage (where a header does not parse, it tries the next byte) -- but it falls in with the true
+// chain as soon as it lands on one real header and stays on it, so the walks merge, and with runs
+// of a few bytes several of the 64 start on real headers to begin with.  The position that most
+// walks have reached when all have passed k * spacing is the guess.  Nothing is trusted: the
+// counting pass that follows walks every segment from its entry and demands that it ends exactly
+// at the next one, and entry 0 is the start of the stream, so a set of entries that passes is, by
+// induction, on the true chain; one that does not is discarded and the stream walked as a single
+// segment.  (Streams of long runs give such walks little to land on: they are not what this is
+// for -- their serial walk is short, a hop per kilobyte.)
+__global__ __launch_bounds__(256) void rlev2_resync_kernel(const uint8_t *__restrict__ s, uint64_t len,
+                                                           int is_signed, uint64_t spacing, uint32_t n_entries,
+                                                           uint64_t *__restrict__ entries) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n_entries) return;  // whole wavefront
+    if (k == 0) {
+        if (lane == 0) entries[0] = 0;
+        return;
+    }
+    uint64_t target = (uint64_t)k * spacing;
+    if (target > len) target = len;
+    uint64_t pos = (uint64_t)(k - 1) * spacing + lane;
+    while (__ballot(pos < target) != 0) {
+        if (pos < target) {
+            ParsedRun r;
+            const uint32_t st = parse_run(load_window(s, len, pos), s, len, pos, is_signed, r);
+            pos = (st == SEG_OK && r.run_end > pos) ? r.run_end : pos + 1;
+        }
+    }
+    if (pos > len) pos = len;
+    // the position most walks agree on
+    uint32_t best_votes = 0;
+    uint64_t best = pos;
+    for (int j = 0; j < 64; j++) {
+        const uint64_t cand = readlane64(pos, j);
+        const uint32_t votes = (uint32_t)__builtin_popcountll(__ballot(pos == cand));
+        if (votes > best_votes) {
+            best_votes = votes;
+            best = cand;
+        }
+    }
+    if (lane == 0) entries[k] = best;
+}
+
 // What rlev2_coop_count_kernel left in t.seg_count, through the workgroup-local scan that the
 // counting kernel proper ends with.
 __global__ __launch_bounds__(SEG_BLOCK) void rlev2_publish_kernel(uint32_t n_seg, SegTable t) {
@@ -1919,6 +1967,13 @@ static hipError_t launch_values_mode(hipStream_t st, const Rlev2Table &t, int64_
         rlev2_values_kernel<MODE, false><<<blocks, VAL_WAVES * 64, 0, st>>>(
             t.stream, t.len, t.runs, t.group_first, t.group_run, t.n_groups, t.n_runs, t.num_values,
             t.is_signed, out, group_sums, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_rlev2_resync(hipStream_t st, const uint8_t *stream, uint64_t len, int is_signed,
+                               uint64_t spacing, uint32_t n_entries, uint64_t *entries) {
+    if (n_entries == 0) return hipSuccess;
+    rlev2_resync_kernel<<<(n_entries + 3) / 4, 256, 0, st>>>(stream, len, is_signed, spacing, n_entries, entries);
     return hipGetLastError();
 }
 

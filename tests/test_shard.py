@@ -100,7 +100,7 @@ class _ExclusiveContext:
         self.seen = []
         self.threads = set()
 
-    def decode_stripe(self, metadata, stripe, footer, columns, check_utf8=True, row_aligned=False):
+    def decode_stripe(self, metadata, stripe, footer, columns, check_utf8=True, row_aligned=False, device=False):
         import threading
         import time
         assert self.lock.acquire(blocking=False), "context entered by two threads at once"
