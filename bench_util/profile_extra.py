@@ -1,0 +1,127 @@
+"""The kernels that no bench.py workload exercises, one case each, for rocprofv3 (kernel trace and
+FETCH_SIZE / WRITE_SIZE passes): a few iterations of one large call, checked once.
+
+    python bench_util/profile_extra.py patched_base | dictionary | byte_rle | scatter
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from orc_format_amd import _native as N  # noqa: E402
+from orc_format_amd import Context  # noqa: E402
+from orc_format_amd.error import check  # noqa: E402
+
+ITERS = 4
+
+
+def timed(ctx, fn):
+    best = 1e9
+    for _ in range(ITERS):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        ctx.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def patched_base(ctx):
+    """2*10^8 values as PatchedBase runs of 512 values, width 8 with 5 % of the values patched to
+    24 bits (64 distinct runs, repeated), entry points every 20 runs."""
+    import rle_encode as enc
+    rng = np.random.default_rng(1)
+    runs, vals = [], []
+    for _ in range(64):
+        v = rng.integers(0, 200, size=512, dtype=np.int64)
+        where = np.cumsum(rng.integers(1, 21, size=25)) - 1     # 25 patched positions, gaps of 1..20
+        v[where] += rng.integers(1 << 12, 1 << 20, size=25)
+        base = int(v.min())
+        low = (v - base) & 0xFF
+        gaps = np.diff(np.concatenate([[0], where]))
+        patches = [(int(g), int((v[i] - base) >> 8)) for g, i in zip(gaps, where)]   # (gap, patch) as stored
+        b = enc.patched_base(base, low, 8, patches, 16, 8)
+        runs.append(b)
+        vals.append(v)
+    size = {len(b) for b in runs}
+    reps = 2 * 10**8 // (64 * 512)
+    stream = torch.from_numpy(np.frombuffer(b"".join(runs), dtype=np.uint8).copy()).cuda().repeat(reps)
+    expect = torch.from_numpy(np.concatenate(vals)).cuda().repeat(reps)
+    starts = np.cumsum([0] + [len(b) for b in runs] * reps)[:-1]
+    entries = torch.from_numpy(starts[::20].astype(np.int64)).cuda()
+    n = expect.numel()
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    dt = timed(ctx, lambda: ctx.rlev2_device(stream.data_ptr(), stream.numel(), n, False, out.data_ptr(),
+                                             entries.data_ptr(), entries.numel()))
+    assert torch.equal(out, expect)
+    print("patched_base: %d values, %d stream bytes (run sizes %s), %.3f ms, %.0f GB/s decoded" %
+          (n, stream.numel(), sorted(size)[:3], dt * 1e3, n * 8 / dt / 1e9), flush=True)
+
+
+def dictionary(ctx):
+    """10^8 indices into a dictionary of 1000 entries of 4..28 bytes: offsets + gathered bytes."""
+    n = 100_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    lens = torch.randint(4, 29, (1000,), device="cuda", generator=g)
+    doff = torch.zeros(1001, dtype=torch.int64, device="cuda")
+    doff[1:] = torch.cumsum(lens, 0)
+    dbytes = torch.randint(97, 123, (int(doff[-1]),), dtype=torch.uint8, device="cuda", generator=g)
+    idx = torch.randint(0, 1000, (n,), dtype=torch.int64, device="cuda", generator=g)
+    want_off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    want_off[1:] = torch.cumsum(lens[idx], 0)
+    total = int(want_off[-1])
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    out = torch.empty(total, dtype=torch.uint8, device="cuda")
+    lib = N.lib()
+    dt = timed(ctx, lambda: check(lib.orcd_string_dictionary_decode(
+        ctx.handle, doff.data_ptr(), dbytes.data_ptr(), 1000, idx.data_ptr(), n, offsets.data_ptr(),
+        out.data_ptr(), total, N.IN_DEVICE | N.OUT_DEVICE), ctx.handle))
+    assert torch.equal(offsets, want_off)
+    print("dictionary: %d values, %d bytes out, %.3f ms, %.0f GB/s of bytes + offsets" %
+          (n, total, dt * 1e3, (total + 8 * n) / dt / 1e9), flush=True)
+
+
+def byte_rle(ctx):
+    """The byte-RLE mix of the boolean workload, decoded to bytes (orcd_byte_rle_decode): 5*10^8
+    bytes out."""
+    from bench_util import synth
+    stream, entries, packed = synth.byte_rle_mix(500_000_000 // 128, device="cuda")
+    n = packed.numel()
+    out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    lib = N.lib()
+    dt = timed(ctx, lambda: check(lib.orcd_byte_rle_decode(
+        ctx.handle, stream.data_ptr(), stream.numel(), n, entries.data_ptr(), entries.numel(), out.data_ptr(),
+        N.IN_DEVICE | N.OUT_DEVICE), ctx.handle))
+    assert torch.equal(out, packed)
+    print("byte_rle: %d stream bytes -> %d bytes, %.3f ms, %.0f GB/s decoded" %
+          (stream.numel(), n, dt * 1e3, n / dt / 1e9), flush=True)
+
+
+def scatter(ctx):
+    """Null scatter: 5*10^8 rows, 10 % nulls, 8-byte values into row positions."""
+    rows = 500_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2)
+    valid = (torch.rand(rows, device="cuda", generator=g) >= 0.1).to(torch.uint8)
+    n_values = int(valid.sum())
+    dense = torch.arange(n_values, dtype=torch.int64, device="cuda")
+    out = torch.empty(rows, dtype=torch.int64, device="cuda")
+    lib = N.lib()
+    dt = timed(ctx, lambda: check(lib.orcd_scatter_valid(
+        ctx.handle, valid.data_ptr(), rows, dense.data_ptr(), n_values, 8, out.data_ptr(),
+        N.IN_DEVICE | N.OUT_DEVICE), ctx.handle))
+    idx = torch.nonzero(valid[:1_000_000]).flatten()
+    assert torch.equal(out[:1_000_000][idx], torch.arange(idx.numel(), dtype=torch.int64, device="cuda"))
+    print("scatter: %d rows, %d values, %.3f ms, %.0f GB/s of rows written" %
+          (rows, n_values, dt * 1e3, rows * 8 / dt / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    {"patched_base": patched_base, "dictionary": dictionary, "byte_rle": byte_rle, "scatter": scatter}[sys.argv[1]](Context(0))

@@ -6,9 +6,14 @@ trace_dir: `rocprofv3 --kernel-trace --stats --output-format csv` of bench.py;
 fetch_dir / write_dir: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the same command.
 Writes <out_prefix>_kernel_stats.csv (the decoder's kernels only) and <out_prefix>_traffic.json.
 
-gfx950 counter corrections applied: FETCH_SIZE and WRITE_SIZE are in KiB-like units of 1024 B... as
-reported by rocprofv3 (kilobytes); FETCH_SIZE tallies 128-byte requests at 64 bytes for wide
-coalesced streaming reads, so the read side is doubled.
+Counter units and the gfx950 correction: rocprofv3 reports FETCH_SIZE and WRITE_SIZE in units of
+1024 bytes.  FETCH_SIZE tallies the 128-byte requests of wide coalesced streaming reads (16 bytes
+per lane) at 64 bytes, so for a kernel whose reads are of that kind the read side is doubled; that
+is calibrated only for such reads.  WIDE_READS below names those kernels (their stream bytes come
+in through 16-byte-per-lane loads of consecutive chunks); for every other kernel -- the header
+scans with their per-lane walks, the gathers, the small table passes -- the raw figure is kept as
+the estimate and the doubled one is given beside it as the upper bound
+(`hbm_read_bytes_per_launch_upper`): the truth lies between the two.
 """
 import collections
 import csv
@@ -16,6 +21,11 @@ import glob
 import json
 import os
 import sys
+
+
+# kernels whose dominant reads are 16 bytes per lane, consecutive lanes consecutive chunks
+WIDE_READS = ("rlev2_values_kernel", "rlev2_strided_values_kernel", "string_bytes_kernel",
+              "byte_rle_exits_kernel", "byte_rle_tile_kernel")
 
 
 def _one(pattern):
@@ -44,8 +54,13 @@ def main():
             traffic.setdefault(k, {})[kind + "_kb_avg"] = sum(v) / len(v)
             traffic[k]["dispatches_" + kind] = len(v)
     for k, t in traffic.items():
-        fetch = t.get("FETCH_SIZE_kb_avg", 0.0) * 1024 * 2   # gfx950: counts half of wide reads
+        raw = t.get("FETCH_SIZE_kb_avg", 0.0) * 1024
+        wide = any(w in k for w in WIDE_READS)
+        fetch = raw * 2 if wide else raw   # gfx950: counts half of wide reads
         write = t.get("WRITE_SIZE_kb_avg", 0.0) * 1024
+        t["read_correction"] = "x2 (wide coalesced reads)" if wide else "none (uncalibrated pattern; upper bound = x2)"
+        if not wide:
+            t["hbm_read_bytes_per_launch_upper"] = raw * 2
         t["hbm_read_bytes_per_launch"] = fetch
         t["hbm_write_bytes_per_launch"] = write
         t["hbm_bytes_per_launch"] = fetch + write

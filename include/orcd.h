@@ -89,6 +89,11 @@ int orcd_ctx_synchronize(orcd_ctx *ctx);
  * temporaries of orcd_decode_column / orcd_decode_stripe) back to the runtime; waits for the
  * context's queued work first.  Nothing else changes: the next call allocates afresh. */
 int orcd_ctx_release_cached(orcd_ctx *ctx);
+/* How many bytes of released result arrays and temporaries of the column calls the context keeps
+ * for its next calls instead of handing them back to the runtime: device memory, and pinned host
+ * memory (defaults 64 GiB and 32 GiB; 0 keeps nothing).  Takes effect from the next release on;
+ * orcd_ctx_release_cached empties what is held now. */
+int orcd_ctx_set_cache_limit(orcd_ctx *ctx, size_t device_bytes, size_t host_bytes);
 /* Copies `bytes` bytes from device memory -- typically one array of an orcd_column_data that was
  * asked for with ORCD_OUT_DEVICE, such as the offsets of a string column whose bytes stay on the
  * GPU -- to host memory, on the context's stream, and waits for it.  (The reference keeps

@@ -61,6 +61,7 @@ SIGNATURES = {
     "orcd_ctx_set_stream": (C.c_int, [P, P]),
     "orcd_ctx_synchronize": (C.c_int, [P]),
     "orcd_ctx_release_cached": (C.c_int, [P]),
+    "orcd_ctx_set_cache_limit": (C.c_int, [P, SZ, SZ]),
     "orcd_ctx_copy_to_host": (C.c_int, [P, P, P, SZ]),
     "orcd_ctx_last_elapsed_ms": (C.c_float, [P]),
     "orcd_ctx_phase_ms": (C.c_float, [P, C.c_int]),

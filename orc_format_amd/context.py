@@ -111,6 +111,9 @@ class Context:
         check(self._lib.orcd_ctx_copy_to_host(self._h, out.ctypes.data, device_ptr, out.nbytes), self._h)
         return out
 
+    def set_cache_limit(self, device_bytes, host_bytes):
+        check(self._lib.orcd_ctx_set_cache_limit(self._h, device_bytes, host_bytes), self._h)
+
     def release_cached(self):
         """Returns the device memory kept for the next column calls to the runtime."""
         check(self._lib.orcd_ctx_release_cached(self._h), self._h)

@@ -132,6 +132,7 @@ extern "C" {
     pub fn orcd_ctx_set_stream(ctx: *mut orcd_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn orcd_ctx_synchronize(ctx: *mut orcd_ctx) -> c_int;
     pub fn orcd_ctx_release_cached(ctx: *mut orcd_ctx) -> c_int;
+    pub fn orcd_ctx_set_cache_limit(ctx: *mut orcd_ctx, device_bytes: usize, host_bytes: usize) -> c_int;
     pub fn orcd_ctx_copy_to_host(ctx: *mut orcd_ctx, dst: *mut c_void, src_device: *const c_void,
                                  bytes: usize) -> c_int;
     pub fn orcd_ctx_last_elapsed_ms(ctx: *mut orcd_ctx) -> c_float;
