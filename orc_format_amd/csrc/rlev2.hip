@@ -1304,18 +1304,34 @@ __device__ __forceinline__ void expand_window_by_marks(const W &wv, uint64_t wba
     __builtin_amdgcn_wave_barrier();  // the slice may be staged into again
 }
 
-// The runs rb, rb + 1, ... of the table that start before `own_end`, as decode_run_batch takes
-// them, when none of them carries a running sum or patches and their bytes fit the LDS slice;
-// MODE_VALUES only.  Returns false, with nothing written, for any other batch (decode_run_batch
-// takes it then); otherwise `next_beg` is the index after the last run's last value.
+// A batch of runs without running sums, planned: everything short_expand needs, with the loads of
+// the window's stream bytes already on their way (so that a wavefront can plan a second window
+// before it expands the first, and the memory hops of the two coincide).
+struct ShortPlan {
+    uint32_t nb;                       // runs of the batch that start inside the window
+    uint64_t batch_beg, batch_all, batch_end, own_end;
+    uint64_t desc;                     // lane k: run k of the batch
+    uint32_t rel;                      // ... its first value relative to batch_beg
+    bool mine, any_linear, wide;
+    uint64_t base, aux;                // lane k: base and step of a Delta run without packed deltas
+    uint64_t b0, b1;                   // stream bytes of the window
+    uint4 chunk;                       // lane c: 16-byte chunk c of them, when they are at most 64 chunks
+    bool prefetched;
+    bool tail_staged;                  // b1 reaches to the end of the last run's bytes
+    uint64_t t_start, t_pay;           // the batch's last run, which alone may reach past the window
+    uint32_t t_len, t_kind, t_w;
+};
+
+constexpr int SHORT_OTHER = 0;    // not a batch of that kind (nothing done: decode_run_batch takes it)
+constexpr int SHORT_NOTHING = 1;  // no run, or every run after the last wanted value
+constexpr int SHORT_PLANNED = 2;
+
+// desc: lane k's descriptor of run rb + k, loaded by the caller (`held`: the table has such a run).
 template <class W>
-__device__ __forceinline__ bool decode_short_batch(const W &wv, const uint64_t *runs, uint32_t rb, uint32_t avail,
-                                                   const uint64_t batch_beg, const uint64_t own_end,
-                                                   uint32_t &nb, uint64_t &next_beg) {
+__device__ __forceinline__ int short_plan(const W &wv, uint64_t desc, bool held, const uint64_t batch_beg,
+                                          const uint64_t own_end, ShortPlan &pl) {
     const int lane = wv.lane;
-    const bool held = (uint32_t)lane < avail;
-    uint64_t desc = make_desc(0, KIND_SHORT_REPEAT, 0, 1, 0, 1);
-    if (held) desc = runs[rb + lane];
+    if (!held) desc = make_desc(0, KIND_SHORT_REPEAT, 0, 1, 0, 1);
     const uint32_t len = held ? desc_len(desc) : 0u;
     const uint32_t incl = wave_scan_dpp(len);
     const uint32_t rel = incl - len;
@@ -1323,35 +1339,51 @@ __device__ __forceinline__ bool decode_short_batch(const W &wv, const uint64_t *
     // table past the window's runs may hold anything; lengths are 1..512 whatever the bits.)
     const uint32_t room = (uint32_t)(own_end - batch_beg);
     const bool mine = held && rel < room;
-    nb = (uint32_t)__builtin_popcountll(__ballot(mine));
-    if (nb == 0) {
-        next_beg = batch_beg;
-        return true;
-    }
+    pl.nb = (uint32_t)__builtin_popcountll(__ballot(mine));
+    pl.batch_beg = batch_beg;
+    pl.batch_all = batch_beg;
+    pl.own_end = own_end;
+    if (pl.nb == 0) return SHORT_NOTHING;
     const uint32_t kind = desc_kind(desc), w = desc_width(desc);
     if (__ballot(mine && !(kind == KIND_SHORT_REPEAT || kind == KIND_DIRECT || (kind == KIND_DELTA && w == 0))))
-        return false;
-    const int last = (int)nb - 1;
-    const uint64_t batch_all = batch_beg + readlane32(incl, last);
-    const uint64_t batch_end = batch_all < wv.num_values ? batch_all : wv.num_values;
-    next_beg = batch_all;
-    if (batch_beg >= batch_end) return true;  // every run of the batch lies after the last wanted value
-    // the batch's last run, which alone may reach past the window
-    const uint64_t t_start = batch_beg + readlane32(rel, last);
-    const uint64_t t_pay = readlane64(desc_payload(desc), last);
-    const uint32_t t_len = readlane32(len, last), t_kind = readlane32(kind, last), t_w = readlane32(w, last);
-    const uint64_t wbase = own_end - WINDOW;
-    const uint64_t hi = own_end < batch_end ? own_end : batch_end;
+        return SHORT_OTHER;
+    const int last = (int)pl.nb - 1;
+    pl.batch_all = batch_beg + readlane32(incl, last);
+    pl.batch_end = pl.batch_all < wv.num_values ? pl.batch_all : wv.num_values;
+    if (batch_beg >= pl.batch_end) return SHORT_NOTHING;  // every run of the batch lies after the last wanted value
+    pl.t_start = batch_beg + readlane32(rel, last);
+    pl.t_pay = readlane64(desc_payload(desc), last);
+    pl.t_len = readlane32(len, last);
+    pl.t_kind = readlane32(kind, last);
+    pl.t_w = readlane32(w, last);
+    const uint64_t hi = own_end < pl.batch_end ? own_end : pl.batch_end;
     // bytes of the window: from the first run's packed bytes to the last byte that the last run's
     // values in front of `hi` take
-    const uint32_t t_count = hi > t_start ? ((hi - t_start) < t_len ? (uint32_t)(hi - t_start) : t_len) : 0u;
-    const uint64_t b0 = readlane64(desc_payload(desc), 0);
-    const uint64_t b1 = t_pay + (t_kind == KIND_DIRECT ? ((uint64_t)t_count * t_w + 7) >> 3
-                                                        : (t_kind == KIND_SHORT_REPEAT ? t_w >> 3 : 0u));
-    if (b1 < b0 || b1 - b0 + 15 > STAGE_BYTES) return false;
-    const bool any_linear = __ballot(mine && kind == KIND_DELTA) != 0;
-    const bool wide = __ballot(mine && kind != KIND_DELTA && w > 32) != 0;
-    uint64_t base = 0, aux = 0;
+    const uint32_t t_count = hi > pl.t_start ? ((hi - pl.t_start) < pl.t_len ? (uint32_t)(hi - pl.t_start) : pl.t_len) : 0u;
+    uint64_t b0 = readlane64(desc_payload(desc), 0);
+    uint64_t b1 = pl.t_pay + (pl.t_kind == KIND_DIRECT ? ((uint64_t)t_count * pl.t_w + 7) >> 3
+                                                         : (pl.t_kind == KIND_SHORT_REPEAT ? pl.t_w >> 3 : 0u));
+    if (b1 > wv.len) b1 = wv.len;  // (never, for a table the header scan made)
+    if (b1 < b0 || b1 - b0 + 15 > STAGE_BYTES) return SHORT_OTHER;
+    // what the last run holds past the window follows right behind: staged along with the rest
+    // when it fits, so that those values cost no memory round trip of their own
+    pl.tail_staged = false;
+    if (pl.batch_end > own_end && pl.t_kind != KIND_DELTA) {
+        uint64_t full = pl.t_pay + (pl.t_kind == KIND_DIRECT ? ((uint64_t)pl.t_len * pl.t_w + 7) >> 3 : pl.t_w >> 3);
+        if (full <= wv.len && full >= b1 && full - b0 + 15 <= STAGE_BYTES) {
+            b1 = full;
+            pl.tail_staged = true;
+        }
+    }
+    pl.b0 = b0;
+    pl.b1 = b1;
+    pl.desc = desc;
+    pl.rel = rel;
+    pl.mine = mine;
+    pl.any_linear = __ballot(mine && kind == KIND_DELTA) != 0;
+    pl.wide = __ballot(mine && kind != KIND_DELTA && w > 32) != 0;
+    pl.base = 0;
+    pl.aux = 0;
     if (mine && kind == KIND_DELTA) {
         // the header scan accepted this header: the parse cannot fail, and reads what it read
         const uint64_t pos = desc_payload(desc) - desc_header_bytes(desc);
@@ -1359,52 +1391,100 @@ __device__ __forceinline__ bool decode_short_batch(const W &wv, const uint64_t *
         r.base = 0;
         r.aux = 0;
         if (pos < wv.len && parse_run(load_window(wv.s, wv.len, pos), wv.s, wv.len, pos, wv.is_signed, r) == SEG_OK) {
-            base = r.base;
-            aux = r.aux;
+            pl.base = r.base;
+            pl.aux = r.aux;
         }
     }
+    // the window's bytes, asked for now: whole aligned 16-byte chunks as stage_bytes reads them
+    pl.prefetched = false;
+    pl.chunk = make_uint4(0, 0, 0, 0);
+    if (b1 > b0) {
+        const uint32_t skew = (uint32_t)((uintptr_t)(wv.s + b0) & 15);
+        const uint32_t n16 = (uint32_t)((b1 - b0 + skew + 15) >> 4);
+        if (n16 <= 64) {
+            pl.prefetched = true;
+            if ((uint32_t)lane < n16) pl.chunk = ((const uint4 *)(wv.s + b0 - skew))[lane];
+        }
+    }
+    return SHORT_PLANNED;
+}
+
+// Decodes what short_plan has planned (MODE_VALUES).
+template <class W>
+__device__ __forceinline__ void short_expand(const W &wv, const ShortPlan &pl) {
+    const int lane = wv.lane;
+    const uint64_t wbase = pl.own_end - WINDOW;
+    const uint64_t hi = pl.own_end < pl.batch_end ? pl.own_end : pl.batch_end;
+    const uint32_t kind = desc_kind(pl.desc), w = desc_width(pl.desc);
     {
-        const uint64_t origin = b1 > b0 ? stage_bytes(wv, b0, b1) : b0;
-        const uint32_t my_ws = mine ? rel + (uint32_t)(batch_beg - wbase) : 0xFFFFFFFFu;
+        uint64_t origin = pl.b0;
+        if (pl.prefetched) {
+            const uint32_t skew = (uint32_t)((uintptr_t)(wv.s + pl.b0) & 15);
+            uint4 v = pl.chunk;  // (chunks past the span are zero and land inside the slice)
+            v.x = __builtin_bswap32(v.x);
+            v.y = __builtin_bswap32(v.y);
+            v.z = __builtin_bswap32(v.z);
+            v.w = __builtin_bswap32(v.w);
+            ((uint4 *)wv.lds)[lane] = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            origin = pl.b0 - skew;
+        } else if (pl.b1 > pl.b0) {
+            origin = stage_bytes(wv, pl.b0, pl.b1);
+        }
+        if (pl.tail_staged) {
+            // the last run's values from own_end on, out of the bytes just staged (before the
+            // window's own expansion takes the slice for its output tile); lane i takes values
+            // i, i + 64, ...
+            const uint32_t first = (uint32_t)(pl.own_end - pl.t_start);
+            const uint32_t end = (uint32_t)(pl.batch_end - pl.t_start);
+            const uint32_t bit0 = (uint32_t)((pl.t_pay - origin) << 3);
+            for (uint32_t idx = first + (uint32_t)lane; idx < end; idx += 64) {
+                const uint64_t m = lds_bits64(wv.lds, bit0 + (pl.t_kind == KIND_DIRECT ? idx * pl.t_w : 0u), pl.t_w);
+                stream_store1(wv.out + pl.t_start + idx, wv.is_signed ? zigzag(m) : m);
+            }
+        }
+        const uint32_t my_ws = pl.mine ? pl.rel + (uint32_t)(pl.batch_beg - wbase) : 0xFFFFFFFFu;
         const uint32_t my_rec = (my_ws & 511u) |
-                                ((((uint32_t)desc_payload(desc) - (uint32_t)origin) & 8191u) << 9) |
+                                ((((uint32_t)desc_payload(pl.desc) - (uint32_t)origin) & 8191u) << 9) |
                                 (w << 22) | (kind << 29);
-        const uint32_t lo_w = (uint32_t)(batch_beg - wbase), hi_w = (uint32_t)(hi - wbase);
-        if (any_linear) {
-            if (wv.is_signed) expand_window_by_marks<true, true, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
-            else expand_window_by_marks<true, true, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
-        } else if (wide) {
-            if (wv.is_signed) expand_window_by_marks<true, false, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
-            else expand_window_by_marks<true, false, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
+        const uint32_t lo_w = (uint32_t)(pl.batch_beg - wbase), hi_w = (uint32_t)(hi - wbase);
+        if (pl.any_linear) {
+            if (wv.is_signed) expand_window_by_marks<true, true, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
+            else expand_window_by_marks<true, true, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
+        } else if (pl.wide) {
+            if (wv.is_signed) expand_window_by_marks<true, false, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
+            else expand_window_by_marks<true, false, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
         } else {
-            if (wv.is_signed) expand_window_by_marks<false, false, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
-            else expand_window_by_marks<false, false, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
+            if (wv.is_signed) expand_window_by_marks<false, false, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
+            else expand_window_by_marks<false, false, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
         }
     }
-    // the windows behind: what the last run holds from own_end on; lane i takes values i, i + 64, ...
-    const uint64_t t_base = readlane64(base, last), t_step = readlane64(aux, last);
-    for (uint64_t wb = own_end; wb < batch_end; wb += WINDOW) {
-        const uint64_t we = (wb + WINDOW) < batch_end ? wb + WINDOW : batch_end;
-        const uint32_t first = (uint32_t)(wb - t_start), end = (uint32_t)(we - t_start);  // indices in the run
+    // the windows behind (unless done above): what the last run holds from own_end on; lane i
+    // takes values i, i + 64, ...
+    const int last = (int)pl.nb - 1;
+    const uint64_t t_base = readlane64(pl.base, last), t_step = readlane64(pl.aux, last);
+    for (uint64_t wb = pl.own_end; wb < pl.batch_end && !pl.tail_staged; wb += WINDOW) {
+        const uint64_t we = (wb + WINDOW) < pl.batch_end ? wb + WINDOW : pl.batch_end;
+        const uint32_t first = (uint32_t)(wb - pl.t_start), end = (uint32_t)(we - pl.t_start);  // indices in the run
         uint32_t bit0 = 0;  // bit in the slice of the run's packed field 0 (modulo 2^32)
-        if (t_kind != KIND_DELTA) {
-            const uint64_t f0 = t_kind == KIND_DIRECT ? ((uint64_t)first * t_w) >> 3 : 0u;
-            const uint64_t f1 = t_kind == KIND_DIRECT ? ((uint64_t)end * t_w + 7) >> 3 : t_w >> 3;
-            const uint64_t origin = stage_bytes(wv, t_pay + f0, t_pay + f1);
-            bit0 = (uint32_t)((t_pay - origin) << 3);
+        if (pl.t_kind != KIND_DELTA) {
+            const uint64_t f0 = pl.t_kind == KIND_DIRECT ? ((uint64_t)first * pl.t_w) >> 3 : 0u;
+            const uint64_t f1 = pl.t_kind == KIND_DIRECT ? ((uint64_t)end * pl.t_w + 7) >> 3 : pl.t_w >> 3;
+            const uint64_t origin = stage_bytes(wv, pl.t_pay + f0, pl.t_pay + f1);
+            bit0 = (uint32_t)((pl.t_pay - origin) << 3);
         }
         for (uint32_t idx = first + (uint32_t)lane; idx < end; idx += 64) {
             uint64_t val = t_base + (uint64_t)idx * t_step;  // Delta without packed deltas
-            if (t_kind != KIND_DELTA) {
-                const uint64_t m = lds_bits64(wv.lds, bit0 + (t_kind == KIND_DIRECT ? idx * t_w : 0u), t_w);
+            if (pl.t_kind != KIND_DELTA) {
+                const uint64_t m = lds_bits64(wv.lds, bit0 + (pl.t_kind == KIND_DIRECT ? idx * pl.t_w : 0u), pl.t_w);
                 val = wv.is_signed ? zigzag(m) : m;
             }
-            stream_store1(wv.out + t_start + idx, val);
+            stream_store1(wv.out + pl.t_start + idx, val);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // the slice may be staged into again
     }
-    return true;
 }
 
 // The runs rb, rb + 1, ... of the table that start before `own_end` (the end of the wavefront's
@@ -1645,7 +1725,8 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
         const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = wg % 8;
         wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
     }
-    const uint32_t g = wg * VAL_WAVES + wave;
+    constexpr bool PAIRED = SHORT && MODE == MODE_VALUES;  // a wavefront takes two neighbouring windows
+    const uint32_t g = (wg * VAL_WAVES + wave) * (PAIRED ? 2 : 1);
     if (g >= n_groups) return;  // whole wavefront leaves; no workgroup barrier is used below
     __shared__ uint32_t marks[VAL_WAVES][WINDOW / 32];
     WaveOf<MODE> wv;
@@ -1662,6 +1743,61 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
     wv.saw_patched = 0;
     if (MODE == MODE_OFFSETS) wv.acc = group_sums[g];  // wave-uniform address
 
+    // The runs that start inside window `win`, 64 at a time from run `rb` on (clamped to the table
+    // so that a bad index can never walk off it); which run is the last follows from the lengths.
+    auto batches_from = [&](uint32_t win, uint64_t rb64, uint64_t beg) {
+        const uint64_t own_end = ((uint64_t)win + 1) << WINDOW_SHIFT;
+        if (rb64 > n_runs) rb64 = n_runs;
+        for (uint32_t rb = (uint32_t)rb64; rb < n_runs && beg < own_end; rb += 64) {
+            uint32_t nb;
+            beg = decode_run_batch(wv, runs, rb, n_runs - rb, beg, own_end, nb);
+            if (nb < 64) break;
+        }
+    };
+
+    if constexpr (PAIRED) {
+        // Two windows per wavefront, so that their dependent memory hops -- the window's copy of
+        // its first run, the descriptors of its runs, the stream bytes -- are taken together:
+        // both are planned before either is expanded.
+        const bool two = g + 1 < n_groups;
+        const RunEntry *e0 = group_run + g, *e1 = group_run + (two ? g + 1 : g);
+        const uint64_t d0 = readfirstlane64(e0->desc), d1 = readfirstlane64(e1->desc);
+        const bool multi0 = !(d0 & DESC_SINGLE), multi1 = two && !(d1 & DESC_SINGLE);
+        uint64_t r0 = multi0 ? readfirstlane64(e0->base) : n_runs, r1 = multi1 ? readfirstlane64(e1->base) : n_runs;
+        if (r0 > n_runs) r0 = n_runs;
+        if (r1 > n_runs) r1 = n_runs;
+        const bool held0 = multi0 && (uint32_t)wv.lane < n_runs - (uint32_t)r0;
+        const bool held1 = multi1 && (uint32_t)wv.lane < n_runs - (uint32_t)r1;
+        uint64_t desc0 = 0, desc1 = 0;
+        if (held0) desc0 = runs[r0 + wv.lane];
+        if (held1) desc1 = runs[r1 + wv.lane];
+        ShortPlan p0, p1;
+        int st0 = SHORT_OTHER, st1 = SHORT_OTHER;
+        if (multi0) st0 = short_plan(wv, desc0, held0, readfirstlane64(e0->out_off), ((uint64_t)g + 1) << WINDOW_SHIFT, p0);
+        if (multi1) st1 = short_plan(wv, desc1, held1, readfirstlane64(e1->out_off), ((uint64_t)g + 2) << WINDOW_SHIFT, p1);
+        // window g
+        if (!multi0) {
+            decode_single_run(wv, d0, readfirstlane64(e0->out_off), readfirstlane64(e0->base), readfirstlane64(e0->aux));
+        } else if (st0 == SHORT_OTHER) {
+            batches_from(g, r0, readfirstlane64(e0->out_off));
+        } else {
+            if (st0 == SHORT_PLANNED) short_expand(wv, p0);
+            if (p0.nb == 64) batches_from(g, r0 + 64, p0.batch_all);  // more than 64 runs start in the window
+        }
+        // window g + 1
+        if (two) {
+            if (!multi1) {
+                decode_single_run(wv, d1, readfirstlane64(e1->out_off), readfirstlane64(e1->base), readfirstlane64(e1->aux));
+            } else if (st1 == SHORT_OTHER) {
+                batches_from(g + 1, r1, readfirstlane64(e1->out_off));
+            } else {
+                if (st1 == SHORT_PLANNED) short_expand(wv, p1);
+                if (p1.nb == 64) batches_from(g + 1, r1 + 64, p1.batch_all);
+            }
+        }
+        return;
+    }
+
     // The window's own copy of its first run: when that run is the only one starting in the
     // window (flagged by the header scan) nothing else has to be loaded.  (One kernel for both
     // kinds of group: a split into two launches with separate register budgets measured no
@@ -1672,22 +1808,8 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
         decode_single_run(wv, desc, readfirstlane64(e->out_off), readfirstlane64(e->base),
                           readfirstlane64(e->aux));
     } else {
-        // the runs that start inside this window, 64 at a time from the first one, whose index
-        // the window's copy carries (clamped to the table so that a bad index can never walk off
-        // it); which run is the last follows from the lengths
-        uint64_t beg = readfirstlane64(e->out_off);  // where the group's first run starts
-        const uint64_t own_end = ((uint64_t)g + 1) << WINDOW_SHIFT;
-        uint64_t r0 = readfirstlane64(e->base);
-        if (r0 > n_runs) r0 = n_runs;
-        for (uint32_t rb = (uint32_t)r0; rb < n_runs && beg < own_end; rb += 64) {
-            uint32_t nb;
-            uint64_t next_beg;
-            if (SHORT && MODE == MODE_VALUES && decode_short_batch(wv, runs, rb, n_runs - rb, beg, own_end, nb, next_beg))
-                beg = next_beg;
-            else
-                beg = decode_run_batch(wv, runs, rb, n_runs - rb, beg, own_end, nb);
-            if (nb < 64) break;
-        }
+        // the window's copy carries the index of its first run
+        batches_from(g, readfirstlane64(e->base), readfirstlane64(e->out_off));
     }
     if (MODE == MODE_SUMS) {
         uint64_t t = wv.acc;
@@ -1958,9 +2080,12 @@ static hipError_t launch_values_mode(hipStream_t st, const Rlev2Table &t, int64_
                                      uint64_t *group_sums, uint32_t *flags) {
     if (t.n_groups == 0) return hipSuccess;
     const uint32_t blocks = (t.n_groups + VAL_WAVES - 1) / VAL_WAVES;
-    // more than two runs per window on average: the variant for short runs
+    // more than two runs per window on average: the variant for short runs (which, when it
+    // writes values, gives a wavefront two windows)
+    const uint32_t pairs = (t.n_groups + 1) / 2;
+    const uint32_t short_blocks = MODE == MODE_VALUES ? (pairs + VAL_WAVES - 1) / VAL_WAVES : blocks;
     if ((uint64_t)t.n_runs > 2ull * t.n_groups)
-        rlev2_values_kernel<MODE, true><<<blocks, VAL_WAVES * 64, 0, st>>>(
+        rlev2_values_kernel<MODE, true><<<short_blocks, VAL_WAVES * 64, 0, st>>>(
             t.stream, t.len, t.runs, t.group_first, t.group_run, t.n_groups, t.n_runs, t.num_values,
             t.is_signed, out, group_sums, flags);
     else
