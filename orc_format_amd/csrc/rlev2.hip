@@ -1244,11 +1244,32 @@ __device__ __forceinline__ void expand_window_by_marks(const W &wv, uint64_t wba
     // index of the run that holds the value in front of this lane's first (-1: none does)
     const uint32_t k_before = wave_scan_dpp(n_starts) - n_starts - 1u;
     uint64_t v[8];
+    // Fields of at most 32 bits, no Delta runs: the word that travels is prepared once per run so
+    // that a value's bit position is one multiply-add -- (bit of field 0 - start * stride + 2^14) :
+    // 16 | stride in bits (the width, or 0 for a ShortRepeat run) : 6 | 64 - width : 6.
+    uint32_t my_narrow = 0;
+    if (!WIDE) {
+        const uint32_t w = (my_rec >> 22) & 127u, stride = (my_rec >> 29) == KIND_DIRECT ? w : 0u;
+        my_narrow = ((((my_rec >> 6) & 0xFFF8u) + 16384u - __umul24(my_rec & 511u, stride)) & 0xFFFFu) |
+                    (stride << 16) | ((64u - (w ? (w > 32 ? 32u : w) : 1u)) << 22);
+    }
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const uint32_t p = 8u * (uint32_t)lane + (uint32_t)t;
         const bool act = p - lo_w < hi_w - lo_w;  // lo_w <= p < hi_w
         const uint32_t k = k_before + (uint32_t)__builtin_popcount(starts & ((2u << t) - 1u));
+        if (!WIDE) {
+            const uint32_t nr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(k << 2), (int)my_narrow);
+            // (lanes with nothing to read look at bit 0 of the slice)
+            const uint32_t bit = act ? __umul24(p, (nr >> 16) & 63u) + (nr & 0xFFFFu) - 16384u : 0u;
+            const uint32_t d = bit >> 5, shr = nr >> 22;
+            const uint64_t x = ((uint64_t)wv.lds[d] << 32) | wv.lds[d + 1];
+            const uint32_t m = (uint32_t)(x >> (shr - (bit & 31u))) & (0xFFFFFFFFu >> (shr - 32u));
+            // (a zigzag field of at most 32 bits: the sign fills the upper half)
+            const uint32_t sign = 0u - (m & 1u);
+            v[t] = SIGNED ? ((uint64_t)sign << 32) | ((m >> 1) ^ sign) : (uint64_t)m;
+            continue;
+        }
         const uint32_t rec = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(k << 2), (int)my_rec);
         const uint32_t w = (rec >> 22) & 127u, kind = rec >> 29;
         const uint32_t idx = p - (rec & 511u);
