@@ -1720,6 +1720,9 @@ struct ColumnStreams {
     orcd_file *file;
     orcd_column *col;
     const StripeBytes *dev;  // the device copy the column's streams lie in
+    // a compressed file: the column's streams were decompressed on the host (the column handle
+    // holds them, starting at plain_host) and copied to the device as they are (plain_dev)
+    const uint8_t *plain_dev = nullptr, *plain_host = nullptr;
     // flags for the stream decoders: streams on the device, ROW_INDEX positions on the host,
     // results stay on the device
     unsigned io() const { return ORCD_OUT_DEVICE | ORCD_IN_DEVICE | ORCD_ENTRIES_HOST; }
@@ -1730,6 +1733,16 @@ struct ColumnStreams {
         *len = 0;
         *entries = nullptr;
         *n_entries = 0;
+        if (plain_host) {
+            const uint8_t *hb = nullptr;
+            size_t hl = 0;
+            const int rc = orcd_column_get_stream(col, kind, &hb, &hl);
+            if (rc == ORCD_INVALID_KIND && !required) return ORCD_OK;
+            if (rc != ORCD_OK) return rc;
+            *bytes = plain_dev + (hb - plain_host);
+            *len = hl;
+            return orcd_column_entry_points(file, col, kind, entries, n_entries);
+        }
         uint64_t off = 0, n = 0;
         const int rc = orcd_column_stream_range(col, kind, &off, &n);
         if (rc == ORCD_INVALID_KIND && !required) return ORCD_OK;
@@ -1996,6 +2009,7 @@ struct StripeJob {
     int type_kind = 0;
     uint64_t n_values = 0;
     bool have_validity = false, batched = false;
+    const uint8_t *plain_dev = nullptr, *plain_host = nullptr;  // (see ColumnStreams)
     Pending p;
     explicit StripeJob(orcd_ctx *c) : p(c) {}
 };
@@ -2046,14 +2060,41 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     // 1. the bytes the columns' streams span, read once and copied once to the device
     orcd_stripe_info si;
     ORCD_TRY(orcd_file_stripe(file, stripe, &si));
+    const bool compressed = orcd_file_compression(file) != 0;
     for (size_t i = 0; i < n_columns; i++) {
         if (columns[i] >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
         (*jobs[i]).type_kind = orcd_file_type_kind(file, columns[i]);
-        ORCD_TRY(orcd_stripe_column_open(file, stripe, footer, columns[i], &(*jobs[i]).col));
+        // (a compressed file: the host reads each column's region and inflates its streams,
+        // src/read/decompress/mod.rs:60-80, and the decompressed streams are what goes to the GPU)
+        if (compressed) ORCD_TRY(orcd_read_stripe_column(file, stripe, footer, columns[i], &(*jobs[i]).col));
+        else ORCD_TRY(orcd_stripe_column_open(file, stripe, footer, columns[i], &(*jobs[i]).col));
     }
     StripeBytes sb;
+    if (compressed) {
+        uint64_t total = 0;
+        std::vector<uint64_t> at(n_columns);
+        for (size_t i = 0; i < n_columns; i++) {
+            const uint8_t *hb;
+            size_t hl;
+            ORCD_TRY(orcd_internal_column_bytes((*jobs[i]).col, &hb, &hl));
+            at[i] = total;
+            total += (hl + 255) & ~(uint64_t)255;
+        }
+        ORCD_TRY(dev_alloc(c, std::max<uint64_t>(total, 256), &stripe_mem.tmp));
+        for (size_t i = 0; i < n_columns; i++) {
+            const uint8_t *hb;
+            size_t hl;
+            ORCD_TRY(orcd_internal_column_bytes((*jobs[i]).col, &hb, &hl));
+            (*jobs[i]).plain_host = hb;
+            (*jobs[i]).plain_dev = (const uint8_t *)stripe_mem.tmp + at[i];
+            if (hl) {
+                const HostSource src = {nullptr, 0, hb};
+                ORCD_TRY(chunked_to_device(c, src, hl, (uint8_t *)stripe_mem.tmp + at[i]));
+            }
+        }
+    }
     sb.lo = ~0ull;
-    for (size_t i = 0; i < n_columns; i++) {
+    for (size_t i = 0; i < n_columns && !compressed; i++) {
         uint64_t off = 0, n = 0;
         ORCD_TRY(orcd_column_region((*jobs[i]).col, &off, &n));
         if (off + n < off) return ORCD_OUT_OF_SPEC;
@@ -2061,22 +2102,24 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
         sb.hi = std::max(sb.hi, off + n);
     }
     if (sb.lo > sb.hi) sb.lo = sb.hi = 0;
-    if (si.offset + sb.lo < si.offset) return ORCD_OUT_OF_SPEC;  // offsets a file cannot have
-    {   // the region must lie inside the file before memory of its size is asked for
-        uint8_t probe;
-        if (sb.hi > sb.lo) ORCD_TRY(orcd_file_read_at(file, si.offset + sb.lo + (sb.hi - sb.lo - 1), 1, &probe));
+    if (!compressed) {
+        if (si.offset + sb.lo < si.offset) return ORCD_OUT_OF_SPEC;  // offsets a file cannot have
+        {   // the region must lie inside the file before memory of its size is asked for
+            uint8_t probe;
+            if (sb.hi > sb.lo) ORCD_TRY(orcd_file_read_at(file, si.offset + sb.lo + (sb.hi - sb.lo - 1), 1, &probe));
+        }
+        ORCD_TRY(dev_alloc(c, sb.hi - sb.lo, &stripe_mem.tmp));
+        sb.d_base = (const uint8_t *)stripe_mem.tmp;
+        const HostSource region = {file, si.offset + sb.lo, nullptr};
+        ORCD_TRY(chunked_to_device(c, region, sb.hi - sb.lo, (uint8_t *)stripe_mem.tmp));
     }
-    ORCD_TRY(dev_alloc(c, sb.hi - sb.lo, &stripe_mem.tmp));
-    sb.d_base = (const uint8_t *)stripe_mem.tmp;
-    const HostSource region = {file, si.offset + sb.lo, nullptr};
-    ORCD_TRY(chunked_to_device(c, region, sb.hi - sb.lo, (uint8_t *)stripe_mem.tmp));
 
     // 2. validity: the small PRESENT streams in one set of launches
     {
         StreamBatch batch;
         uint64_t arena_bytes = 0;
         for (size_t i = 0; i < n_columns; i++) {
-            const ColumnStreams cs{file, (*jobs[i]).col, &sb};
+            const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev, (*jobs[i]).plain_host};
             const uint64_t rows = orcd_column_number_of_rows((*jobs[i]).col);
             const uint8_t *b;
             size_t l, n_ent;
@@ -2112,7 +2155,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     }
     for (size_t i = 0; i < n_columns; i++) {
         if ((*jobs[i]).have_validity) continue;
-        const ColumnStreams cs{file, (*jobs[i]).col, &sb};
+        const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev, (*jobs[i]).plain_host};
         ORCD_TRY(column_validity(c, cs, (*jobs[i]).p, &(*jobs[i]).n_values));
     }
     // 3. the small DATA streams of the integer columns in one set of launches
@@ -2124,7 +2167,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
             int enc = 0;
             if (orcd_column_encoding((*jobs[i]).col, &enc, nullptr) != ORCD_OK || enc != ORCD_ENC_DIRECT_V2)
                 continue;  // RLE v1 or unknown: reported per column below
-            const ColumnStreams cs{file, (*jobs[i]).col, &sb};
+            const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev, (*jobs[i]).plain_host};
             const uint8_t *b;
             size_t l, n_ent;
             const uint64_t *ent;
@@ -2160,7 +2203,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     }
     // 4. everything else, column by column
     for (size_t i = 0; i < n_columns; i++) {
-        const ColumnStreams cs{file, (*jobs[i]).col, &sb};
+        const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev, (*jobs[i]).plain_host};
         ORCD_TRY(column_values(c, cs, (*jobs[i]).type_kind, flags, (*jobs[i]).p, (*jobs[i]).n_values, (*jobs[i]).batched,
                                &out[i]));
     }
@@ -2173,7 +2216,7 @@ int orcd_decode_stripe(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
                        const uint32_t *columns, size_t n_columns, unsigned flags, orcd_column_data *out) try {
     if (!c || !file || !footer || (n_columns && (!columns || !out))) return ORCD_INVALID_ARGUMENT;
     for (size_t i = 0; i < n_columns; i++) memset(&out[i], 0, sizeof(out[i]));
-    if (orcd_file_compression(file) != 0) return ORCD_UNSUPPORTED;  // chunk framing is not decoded here
+    if (orcd_file_compression(file) > 1) return ORCD_UNSUPPORTED;  // None and Zlib, as the reference
     DeviceGuard g(c->device);
     std::vector<std::unique_ptr<StripeJob>> jobs;
     for (size_t i = 0; i < n_columns; i++) jobs.emplace_back(new StripeJob(c));

@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <utility>
+#include <zlib.h>
 
 #include "../../include/orcd.h"
 
@@ -138,6 +140,7 @@ struct Source {
 struct orcd_file {
     Source src;
     int compression = 0;
+    uint64_t compression_block = 256 * 1024;  // PostScript.compressionBlockSize: most a chunk decompresses to
     uint64_t number_of_rows = 0;
     uint32_t row_index_stride = 0;
     std::vector<orcd_stripe_info> stripes;
@@ -153,6 +156,14 @@ struct orcd_stripe_footer {
 struct orcd_column {
     bool has_data = true;       // false: a handle without the column's bytes (orcd_stripe_column_open)
     std::vector<uint8_t> data;  // all non-ROW_INDEX streams of the column, in file order
+    // A compressed file (CompressionKind ZLIB): `data` holds the streams decompressed, back to
+    // back, stream k at plain_off[k] with plain_len[k] bytes (k counts the column's non-ROW_INDEX
+    // streams in file order), and per stream the chunk table of the compressed form -- offset of
+    // each chunk header in the compressed stream and of its first byte in the decompressed one --
+    // which is what ROW_INDEX positions of such a file refer to.
+    bool compressed = false;
+    std::vector<uint64_t> plain_off, plain_len;
+    std::vector<std::vector<std::pair<uint64_t, uint64_t>>> chunks;
     uint32_t column = 0;
     uint64_t number_of_rows = 0;
     size_t stripe = 0;
@@ -164,6 +175,64 @@ struct orcd_column {
 };
 
 namespace {
+
+// ORC compression chunks (src/read/decompress/mod.rs:9-17, 60-80): a 3-byte little-endian header,
+// bit 0 "the bytes that follow are not compressed", the rest their number; a compressed chunk is
+// a raw deflate stream.  Appends the decompressed bytes of src[0, n) to `out`; `chunks` (nullable)
+// receives (offset of the chunk header in src, offset of its first byte in out - out's size on
+// entry).  A header or chunk that reaches past the end, or bytes that do not inflate: the
+// reference panics or fails with Error::Decompression -- ORCD_DECOMPRESSION here.
+int inflate_chunks(const uint8_t *src, size_t n, uint64_t block, std::vector<uint8_t> &out,
+                   std::vector<std::pair<uint64_t, uint64_t>> *chunks) {
+    const size_t out0 = out.size();
+    size_t pos = 0;
+    if (block > (1ull << 30)) block = 1ull << 30;  // (whatever the PostScript claims)
+    while (pos < n) {
+        if (n - pos < 3) return ORCD_DECOMPRESSION;
+        const uint32_t h = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
+        const bool original = h & 1;
+        const size_t len = h >> 1;
+        if (chunks) chunks->push_back({(uint64_t)pos, (uint64_t)(out.size() - out0)});
+        pos += 3;
+        if (len > n - pos) return ORCD_DECOMPRESSION;
+        if (original) {
+            out.insert(out.end(), src + pos, src + pos + len);
+        } else if (len) {
+            z_stream zs;
+            memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) return ORCD_NO_MEMORY;
+            zs.next_in = const_cast<Bytef *>(src + pos);
+            zs.avail_in = (uInt)len;
+            int zrc = Z_OK;
+            const size_t chunk_at = out.size();
+            while (zrc != Z_STREAM_END) {
+                const size_t at = out.size();
+                // (no chunk decompresses to more than the file's compression block size: damaged
+                // bytes must not make this grow without bound)
+                if (at - chunk_at > block) {
+                    zrc = Z_DATA_ERROR;
+                    break;
+                }
+                const size_t room = std::min<size_t>(std::max<size_t>(4 * len, 1 << 16), (size_t)(block - (at - chunk_at)) + 1);
+                out.resize(at + room);
+                zs.next_out = out.data() + at;
+                zs.avail_out = (uInt)room;
+                zrc = inflate(&zs, Z_NO_FLUSH);
+                out.resize(at + (room - zs.avail_out));
+                if (zrc != Z_OK && zrc != Z_STREAM_END) break;        // data error, or input exhausted
+                if (zrc == Z_OK && zs.avail_in == 0 && zs.avail_out != 0) break;  // ends before the stream does
+            }
+            inflateEnd(&zs);
+            if (zrc != Z_STREAM_END) return ORCD_DECOMPRESSION;
+        }
+        pos += len;
+    }
+    return ORCD_OK;
+}
+
+// A footer-like section as the protobuf reader wants it: the bytes themselves, or decompressed
+// (src/read/mod.rs:161-183).
+int plain_section(const orcd_file *f, const uint8_t *p, size_t n, std::vector<uint8_t> &out);
 
 int parse_tail(orcd_file *f) {
     const Source &s = f->src;
@@ -185,12 +254,14 @@ int parse_tail(orcd_file *f) {
             if (wire != 0) continue;
             if (field == 1) { footer_length = v; has_footer_length = true; }
             else if (field == 2) f->compression = (int)v;
+            else if (field == 3) f->compression_block = v;
             else if (field == 5) metadata_length = v;
         }
         if (!c.ok) return ORCD_INVALID_PROTO;
     }
     if (!has_footer_length) return ORCD_OUT_OF_SPEC;  // src/read/mod.rs:73
-    if (f->compression != 0) return ORCD_UNSUPPORTED;  // only CompressionKind::None is decoded
+    // CompressionKind None and Zlib, as the reference (decompress/mod.rs:60-82: the rest is todo!())
+    if (f->compression != 0 && f->compression != 1) return ORCD_UNSUPPORTED;
     uint64_t need;
     if (!add3_ok(1 + ps_len, footer_length, metadata_length, need) || need > s.len) return ORCD_OUT_OF_SPEC;
     if (need > tail_len) {  // the crate panics here; re-read the tail at its exact size
@@ -200,7 +271,10 @@ int parse_tail(orcd_file *f) {
     // (need <= tail_len now, so the footer lies inside the buffer)
     if (footer_length > tail_len - 1 - ps_len) return ORCD_OUT_OF_SPEC;
     const uint8_t *footer_end = tail.data() + tail_len - 1 - ps_len;
-    Cursor c{footer_end - footer_length, footer_end};
+    std::vector<uint8_t> footer;
+    const int frc = plain_section(f, footer_end - footer_length, footer_length, footer);
+    if (frc != ORCD_OK) return frc;
+    Cursor c{footer.data(), footer.data() + footer.size()};
     uint32_t field, wire;
     uint64_t v;
     Cursor sub{nullptr, nullptr};
@@ -240,6 +314,15 @@ int parse_tail(orcd_file *f) {
     }
     if (!c.ok) return ORCD_INVALID_PROTO;
     return ORCD_OK;
+}
+
+int plain_section(const orcd_file *f, const uint8_t *p, size_t n, std::vector<uint8_t> &out) {
+    out.clear();
+    if (f->compression == 0) {
+        out.assign(p, p + n);
+        return ORCD_OK;
+    }
+    return inflate_chunks(p, n, f->compression_block, out, nullptr);
 }
 
 int parse_stripe_footer(const std::vector<uint8_t> &buf, orcd_stripe_footer *out) {
@@ -327,16 +410,37 @@ int load_entry_points(orcd_file *file, orcd_column *col) {
         bool present = false;
         for (const auto &s : ft->streams) present = present || (s.column == col->column && s.kind == kind);
         if (!present) continue;
-        const int n = positions_of(type_kind, encoding, kind);
+        int n = positions_of(type_kind, encoding, kind);
         if (n < 0) return ORCD_OK;  // a layout this reader does not know: no entry points
+        // in a compressed file a position starts with the offset of a compression chunk in the
+        // stream, and the byte offset that follows counts inside that chunk's decompressed bytes
+        if (n > 0 && file->compression != 0) n++;
         if (n > 0) slots.push_back({kind, cursor});
         cursor += n;
     }
+    // (a handle without the column's bytes has no chunk tables to translate such positions with)
+    if (file->compression != 0 && !col->compressed) return ORCD_OK;
     std::vector<uint8_t> buf;
     const orcd_stripe_info &si = file->stripes[col->stripe];
     uint64_t index_at;
     if (!add_ok(si.offset, index->offset, index_at) || !file->src.read_at(index_at, index->length, buf))
         return ORCD_OUT_OF_SPEC;
+    if (file->compression != 0) {
+        std::vector<uint8_t> plain;
+        const int prc = plain_section(file, buf.data(), buf.size(), plain);
+        if (prc != ORCD_OK) return prc;
+        buf.swap(plain);
+    }
+    // which of the column's non-ROW_INDEX streams (in file order) each stream kind is
+    int stream_no[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    {
+        int k = 0;
+        for (const auto &s : ft->streams) {
+            if (s.column != col->column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
+            if (s.kind < 8) stream_no[s.kind] = k;
+            k++;
+        }
+    }
     Cursor c{buf.data(), buf.data() + buf.size()};
     uint32_t field, wire;
     uint64_t v;
@@ -358,7 +462,22 @@ int load_entry_points(orcd_file *file, orcd_column *col) {
         }
         for (const auto &sl : slots) {
             std::vector<uint64_t> &e = col->entries[sl.kind];
-            const uint64_t off = pos[sl.first];
+            uint64_t off = pos[sl.first];
+            if (file->compression != 0) {
+                // chunk offset -> where that chunk's bytes start in the decompressed stream
+                const int k = stream_no[sl.kind];
+                if (k < 0 || (size_t)k >= col->chunks.size()) continue;
+                const auto &table = col->chunks[k];
+                auto it = std::lower_bound(table.begin(), table.end(), std::make_pair(off, (uint64_t)0));
+                if (it == table.end() || it->first != off) {  // not a chunk of this stream: no entry points
+                    for (auto &x : col->entries) x.clear();
+                    return ORCD_OK;
+                }
+                if (!add_ok(it->second, pos[sl.first + 1], off) || off > col->plain_len[k]) {
+                    for (auto &x : col->entries) x.clear();
+                    return ORCD_OK;
+                }
+            }
             if (e.empty() || off > e.back()) e.push_back(off);  // ascending, no duplicates
         }
     }
@@ -438,9 +557,12 @@ int orcd_read_stripe_footer(orcd_file *f, size_t stripe, orcd_stripe_footer **ou
     if (!add3_ok(si.offset, si.index_length, si.data_length, footer_at) ||
         !f->src.read_at(footer_at, si.footer_length, buf))
         return ORCD_OUT_OF_SPEC;
+    std::vector<uint8_t> plain;
+    const int prc = plain_section(f, buf.data(), buf.size(), plain);
+    if (prc != ORCD_OK) return prc;
     orcd_stripe_footer *ft = new orcd_stripe_footer();
     ft->stripe = stripe;
-    const int rc = parse_stripe_footer(buf, ft);
+    const int rc = parse_stripe_footer(plain, ft);
     if (rc != ORCD_OK) {
         delete ft;
         return rc;
@@ -488,11 +610,46 @@ int orcd_read_stripe_column(orcd_file *f, size_t stripe, const orcd_stripe_foote
     col->number_of_rows = f->stripes[stripe].number_of_rows;
     col->stripe = stripe;
     col->footer = ft;
+    if (f->compression != 0) {
+        // every stream is a chain of compression chunks of its own (src/read/column.rs:38-55 wraps
+        // the stream's slice in a Decompressor): decompress them all now, back to back
+        std::vector<uint8_t> plain;
+        uint64_t start2 = 0;
+        for (const auto &s : ft->streams) {
+            if (s.column != column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
+            if (start2 > col->data.size() || s.length > col->data.size() - start2) {
+                delete col;
+                return ORCD_OUT_OF_SPEC;
+            }
+            while (plain.size() & 15) plain.push_back(0);  // streams start 16-byte aligned
+            col->plain_off.push_back(plain.size());
+            col->chunks.emplace_back();
+            const int rc = inflate_chunks(col->data.data() + start2, (size_t)s.length, f->compression_block, plain, &col->chunks.back());
+            if (rc != ORCD_OK) {
+                delete col;
+                return rc;
+            }
+            col->plain_len.push_back(plain.size() - col->plain_off.back());
+            start2 += s.length;
+        }
+        col->data.swap(plain);
+        col->compressed = true;
+    }
     *out = col;
     return ORCD_OK;
 } ORCD_CATCH
 
 void orcd_column_free(orcd_column *col) { delete col; }
+
+// (not part of include/orcd.h: for the column calls of orcd_api.hip) the bytes a column handle
+// holds -- of a compressed file: its streams decompressed, which is where orcd_column_get_stream
+// points into.
+int orcd_internal_column_bytes(const orcd_column *col, const uint8_t **bytes, size_t *len) {
+    if (!col || !bytes || !len || !col->has_data) return ORCD_INVALID_ARGUMENT;
+    *bytes = col->data.data();
+    *len = col->data.size();
+    return ORCD_OK;
+}
 
 int orcd_stripe_column_open(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft, uint32_t column,
                             orcd_column **out) try {
@@ -562,8 +719,16 @@ int orcd_column_get_stream(const orcd_column *col, int kind, const uint8_t **byt
     if (!col || !bytes || !len || !col->has_data) return ORCD_INVALID_ARGUMENT;
     // running offset over the column's non-ROW_INDEX streams (src/read/column.rs:38-55)
     uint64_t start = 0;
+    size_t k = 0;
     for (const auto &s : col->footer->streams) {
         if (s.column != col->column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
+        if (col->compressed && (int)s.kind == kind) {
+            if (k >= col->plain_off.size()) return ORCD_OUT_OF_SPEC;
+            *bytes = col->data.data() + col->plain_off[k];
+            *len = (size_t)col->plain_len[k];
+            return ORCD_OK;
+        }
+        k++;
         if ((int)s.kind == kind) {
             if (start > col->data.size() || s.length > col->data.size() - start) return ORCD_OUT_OF_SPEC;
             *bytes = col->data.data() + start;

@@ -100,6 +100,11 @@ struct ByteRun {
     uint64_t out_off;
 };
 
+// (orcd_host.cpp, not part of include/orcd.h) the bytes a column handle holds: its region of the
+// file, or for a compressed file its streams decompressed and 16-byte aligned, back to back --
+// what orcd_column_get_stream points into.
+extern "C" int orcd_internal_column_bytes(const orcd_column *col, const uint8_t **bytes, size_t *len);
+
 // ---- launchers (defined in the .hip files, called from the C ABI layer) ---------------------
 struct SegTable;  // seg_scan.h
 

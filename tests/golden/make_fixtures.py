@@ -2,8 +2,8 @@
 
 The reference generates its fixtures with `pyorc` (write.py:77-116), which is not installed
 here; `pyorc` wraps the same Apache ORC C++ writer, so `pyarrow.orc.write_table` picks the same
-RLE v2 sub-encodings for the same rows.  Only the uncompressed files are produced: zlib is out of
-scope for the decoder.  One known difference: the current writer omits the PRESENT stream of a
+RLE v2 sub-encodings for the same rows.  The uncompressed files are produced here, the zlib
+ones by make_zlib_fixtures.py.  One known difference: the current writer omits the PRESENT stream of a
 column without nulls, where the reference's tests assume it always exists.
 
 Run from the repository root:  python tests/golden/make_fixtures.py

@@ -1,7 +1,7 @@
 """Minimal pure-Python reader of the ORC file tail and stripe footers (test helper).
 
 Independent of the C++ host library, so that tests can (a) hand raw stream bytes to the oracle
-and (b) cross-check the host library's own parsing.  Handles uncompressed files only.
+and (b) cross-check the host library's own parsing.  Handles uncompressed and zlib-compressed files (python's zlib, raw deflate chunks).
 Field numbers are those of the ORC protobuf schema (reference: src/proto.rs:89-278).
 """
 from collections import namedtuple
@@ -59,6 +59,22 @@ def _packed_varints(v, wt):
     return out
 
 
+def inflate_chunks(buf):
+    """ORC compression chunks (decompress/mod.rs:9-17, 60-80) -> plain bytes and the chunk table
+    [(offset of the chunk header in buf, offset of its bytes in the result)]."""
+    import zlib
+    out, table, pos = bytearray(), [], 0
+    while pos < len(buf):
+        h = buf[pos] | (buf[pos + 1] << 8) | (buf[pos + 2] << 16)
+        table.append((pos, len(out)))
+        n = h >> 1
+        chunk = bytes(buf[pos + 3:pos + 3 + n])
+        assert len(chunk) == n
+        out += chunk if h & 1 else zlib.decompressobj(-15).decompress(chunk)
+        pos += 3 + n
+    return bytes(out), table
+
+
 class OrcFile:
     def __init__(self, path):
         with open(path, "rb") as f:
@@ -75,8 +91,8 @@ class OrcFile:
                 self.compression = v
             elif fno == 5:
                 self.metadata_length = v
-        assert self.compression == 0, "test helper reads uncompressed files only"
-        footer = b[-1 - ps_len - self.footer_length:-1 - ps_len]
+        assert self.compression in (0, 1), "test helper reads uncompressed and zlib files only"
+        footer = self._plain(b[-1 - ps_len - self.footer_length:-1 - ps_len])
         self.stripes = []
         self.types = []
         self.number_of_rows = 0
@@ -100,10 +116,13 @@ class OrcFile:
             elif fno == 8:
                 self.row_index_stride = v
 
+    def _plain(self, buf):
+        return inflate_chunks(buf)[0] if self.compression else buf
+
     def stripe_footer(self, stripe):
         s = self.stripes[stripe]
         start = s.offset + s.index_length + s.data_length
-        buf = self.bytes[start:start + s.footer_length]
+        buf = self._plain(self.bytes[start:start + s.footer_length])
         streams, encodings = [], []
         offset = s.offset
         for fno, wt, v in fields(buf):
@@ -121,11 +140,19 @@ class OrcFile:
         return streams, encodings
 
     def stream(self, stripe, column, kind):
-        """Raw bytes of one stream, or None when the column has no such stream."""
+        """Bytes of one stream (decompressed), or None when the column has no such stream."""
         streams, _ = self.stripe_footer(stripe)
         for st in streams:
             if st.column == column and st.kind == kind:
-                return self.bytes[st.offset:st.offset + st.length]
+                return self._plain(self.bytes[st.offset:st.offset + st.length])
+        return None
+
+    def chunk_table(self, stripe, column, kind):
+        """The chunk table of a compressed stream (see inflate_chunks)."""
+        streams, _ = self.stripe_footer(stripe)
+        for st in streams:
+            if st.column == column and st.kind == kind:
+                return inflate_chunks(self.bytes[st.offset:st.offset + st.length])[1]
         return None
 
     def row_index_positions(self, stripe, column):

@@ -1,0 +1,110 @@
+"""CompressionKind ZLIB (src/read/decompress/mod.rs:9-93): the host inflates the compression
+chunks, the GPU decodes the same streams as ever.  The reference's compressed tests
+(tests/it/main.rs:189-196, 233-247, 269-285, 288-296), a zlib twin of the mixed fixture against its
+uncompressed original and pyarrow, and a file whose chunks end inside values."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from orc_format_amd import default_context
+    return default_context()
+
+
+def column(ctx, path, col, stripe=0, **kw):
+    from orc_format_amd import read
+    md = read.read_metadata(path)
+    footer = read.read_stripe_footer(md, stripe)
+    return ctx.decode_column(md, stripe, footer, col, **kw)
+
+
+def strings_of(c):
+    b = c["bytes"].tobytes()
+    o = c["offsets"]
+    return [b[o[i]:o[i + 1]].decode() for i in range(len(o) - 1)]
+
+
+def test_read_bool_compressed(ctx, golden_dir):
+    c = column(ctx, os.path.join(golden_dir, "long_bool_gzip.orc"), 1)
+    assert c["validity"].tolist() == [True] * 32 and c["values"].astype(bool).tolist() == [True] * 32
+
+
+def test_read_string_dict_gzip(ctx, golden_dir):
+    c = column(ctx, os.path.join(golden_dir, "string_dict_gzip.orc"), 1)
+    assert c["validity"].tolist() == [True] * 64
+    assert strings_of(c) == ["abc", "efgh"] * 32
+
+
+def test_read_string_long_long_gzip(ctx, golden_dir):
+    c = column(ctx, os.path.join(golden_dir, "string_long_long_gzip.orc"), 1)
+    assert c["validity"].tolist() == [True] * 10000
+    assert strings_of(c) == ["abcd", "efgh"] * 5000
+
+
+def test_read_f32_long_long_gzip(ctx, golden_dir):
+    """main.rs:288-296 only checks the lengths (its values are random); these are written here."""
+    c = column(ctx, os.path.join(golden_dir, "f32_long_long_gzip.orc"), 1)
+    assert c["validity"].size == 10**6 and c["validity"].all()
+    assert c["values"].dtype == np.float32
+    assert (c["values"] == np.tile(np.array([1.0, 2.0, 4.0, 5.0], dtype=np.float32), 250000)).all()
+
+
+def test_mixed_zlib_equals_uncompressed_and_pyarrow(ctx, golden_dir):
+    po = pytest.importorskip("pyarrow.orc")
+    from orc_format_amd import read
+    plain = os.path.join(golden_dir, "mixed_compression.orc")
+    packed = os.path.join(golden_dir, "mixed_zlib.orc")
+    table = po.ORCFile(packed).read()
+    md = read.read_metadata(packed)
+    n_cols = len(md.types) - 1
+    got = [[] for _ in range(n_cols)]
+    for s in range(len(md.stripes)):
+        footer = read.read_stripe_footer(md, s)
+        cols = ctx.decode_stripe(md, s, footer, list(range(1, n_cols + 1)), row_aligned=True)
+        for k, c in enumerate(cols):
+            got[k].append(c)
+    md0 = read.read_metadata(plain)
+    ref = ctx.decode_stripe(md0, 0, read.read_stripe_footer(md0, 0), list(range(1, n_cols + 1)), row_aligned=True)
+    for k in range(n_cols):
+        valid = np.concatenate([c["validity"] for c in got[k]])
+        assert (valid == ref[k]["validity"]).all()
+        expect = table.column(k).to_pylist()
+        assert valid.tolist() == [x is not None for x in expect]
+        if "values" in ref[k]:
+            vals = np.concatenate([c["values"] for c in got[k]])
+            assert vals.dtype == ref[k]["values"].dtype
+            assert (vals.view(np.uint8) == ref[k]["values"].view(np.uint8)).all()
+        else:
+            strs = sum((strings_of(c) for c in got[k]), [])
+            assert strs == strings_of(ref[k])
+            assert [s for s, v in zip(strs, valid) if v] == [x for x in expect if x is not None]
+
+
+def test_chunks_that_end_inside_values(ctx, tmp_path):
+    """A file of 97-byte compression chunks (bench_util/orc_write.py), decoded stripe by stripe with
+    the columns left on the GPU, against what was written."""
+    from bench_util import orc_write
+    from orc_format_amd import Context, read, shard
+    path = str(tmp_path / "z.orc")
+    templates, _ = orc_write.write_string_file(path, 5, 3000, seed=9, compression_block=97)
+    md = read.read_metadata(path)
+    assert int(md.compression) == 1
+    extra = Context(0)
+
+    def on_stripe(context, stripe, cols):
+        col = cols[0]
+        out = (context.copy_to_host(col.offsets_ptr, col.num_slots + 1, np.int64),
+               context.copy_to_host(col.bytes_ptr, col.num_bytes, np.uint8))
+        col.free()
+        return out
+    res = shard.decode_file_shard(ctx, md, 0, 1, columns=[1], row_aligned=False, extra_contexts=[extra],
+                                  device=True, on_stripe=on_stripe)
+    for stripe, _, (offsets, data) in res:
+        lengths, want = templates[stripe % len(templates)]
+        assert (np.diff(offsets) == lengths.astype(np.int64)).all() and (data == want).all()
+    extra.close()

@@ -15,7 +15,10 @@ from orc_format_amd.proto import ColumnEncodingKind, StreamKind
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIXTURES = ["test.orc", "long_bool.orc", "string_long.orc", "string_dict.orc",
-            "string_long_long.orc", "mixed_compression.orc", "mixed_speed.orc"]
+            "string_long_long.orc", "mixed_compression.orc", "mixed_speed.orc",
+            # CompressionKind ZLIB (src/read/decompress/mod.rs:60-80): footers and streams in chunks
+            "long_bool_gzip.orc", "string_dict_gzip.orc", "string_long_long_gzip.orc",
+            "f32_long_long_gzip.orc", "mixed_zlib.orc"]
 
 
 def test_library_exports_every_declared_symbol():
@@ -104,7 +107,7 @@ def test_metadata_matches_python_parse(golden_dir, name):
     path = os.path.join(golden_dir, name)
     ref = op.OrcFile(path)
     md = read.read_metadata(path)
-    assert md.compression == 0
+    assert md.compression == ref.compression == (1 if ("gzip" in name or "zlib" in name) else 0)
     assert md.number_of_rows == ref.number_of_rows
     assert md.row_index_stride == ref.row_index_stride
     assert md.types == [t[0] for t in ref.types]
@@ -209,7 +212,7 @@ def test_large_tail_is_reread(tmp_path):
     assert len(md.types) == 401 and md.number_of_rows == 3
 
 
-@pytest.mark.parametrize("name", ["mixed_compression.orc", "mixed_speed.orc"])
+@pytest.mark.parametrize("name", ["mixed_compression.orc", "mixed_speed.orc", "mixed_zlib.orc"])
 def test_entry_points_are_run_starts(oracle, golden_dir, name):
     path = os.path.join(golden_dir, name)
     ref = op.OrcFile(path)
@@ -243,3 +246,36 @@ def test_entry_points_are_run_starts(oracle, golden_dir, name):
                     pos += 2 if c < 128 else 1 + 256 - c
                 assert set(entries.tolist()) <= starts, (si, col)
     assert checked > 8
+
+
+def test_compression_chunks(tmp_path):
+    """Chunk framing by hand (decompress/mod.rs:9-17, 154-176): chunks that end inside values,
+    chunks stored as they are, a stream of many chunks -- through a file written by
+    bench_util/orc_write.py with compression -- and broken chunks as errors."""
+    import zlib
+    from bench_util import orc_write
+    rng = np.random.default_rng(3)
+    path = str(tmp_path / "z.orc")
+    templates, size = orc_write.write_string_file(path, 3, 2000, seed=5, compression_block=97)
+    ref = op.OrcFile(path)
+    assert ref.compression == 1
+    md = read.read_metadata(path)
+    assert md.number_of_rows == 6000 and len(md.stripes) == 3
+    for si in range(3):
+        footer = read.read_stripe_footer(md, si)
+        column = read.read_stripe_column(md, si, footer, 1)
+        lengths, data = templates[si % len(templates)]
+        assert bytes(column.get_stream(StreamKind.Data)) == data.tobytes() == ref.stream(si, 1, op.DATA)
+        assert bytes(column.get_stream(StreamKind.Length)) == ref.stream(si, 1, op.LENGTH)
+        assert len(ref.chunk_table(si, 1, op.DATA)) > 100   # random text: stored as it is, in 97-byte chunks
+    # a chunk that announces more bytes than the file holds / bytes that do not inflate
+    with open(path, "rb") as f:
+        image = bytearray(f.read())
+    st = ref.stripes[0]
+    bad = bytearray(image)
+    bad[st.offset] |= 0xFE; bad[st.offset + 1] = 0xFF; bad[st.offset + 2] = 0xFF
+    md2 = read.read_metadata(bytes(bad))
+    with pytest.raises(OrcError) as e:
+        read.read_stripe_column(md2, 0, read.read_stripe_footer(md2, 0), 1)
+    assert e.value.variant == "Decompression"
+    _ = (zlib, rng)
