@@ -36,3 +36,35 @@ def test_file_reads_back(tmp_path, oracle, n_stripes, per_stripe):
         assert bytes(column.get_stream(StreamKind.Data)) == data.tobytes()
         rc, got, consumed = oracle.rlev2(column.get_stream(StreamKind.Length), per_stripe, False)
         assert rc == 0 and (got == lengths.astype(np.int64)).all()
+
+
+def test_compression_chunk_headers_match_the_reference_vectors():
+    """decompress/mod.rs:158-176: `0b 00 00` is 5 bytes stored as they are, `40 0d 03` is 100 000
+    compressed bytes -- the writer's headers and the test parser's reading of them."""
+    import orc_pyparse as op
+    framed = orc_write.chunked(b"hello", 100)
+    assert framed == bytes([0x0B, 0x00, 0x00]) + b"hello"
+    assert op.inflate_chunks(framed) == (b"hello", [(0, 0)])
+    h = (100_000 << 1) | 0
+    assert bytes([h & 0xFF, (h >> 8) & 0xFF, h >> 16]) == bytes([0x40, 0x0D, 0x03])
+    zeros = bytes(1000)
+    framed = orc_write.chunked(zeros, 300)            # four chunks, each deflated
+    plain, table = op.inflate_chunks(framed)
+    assert plain == zeros and [t[1] for t in table] == [0, 300, 600, 900]
+    assert all(framed[t[0]] & 1 == 0 for t in table)
+
+
+@pytest.mark.parametrize("block", [64, 4096])
+def test_compressed_file_reads_back(tmp_path, block):
+    po = pytest.importorskip("pyarrow.orc")
+    path = str(tmp_path / "z.orc")
+    templates, size = orc_write.write_string_file(path, 3, 700, seed=4, compression_block=block)
+    f = po.ORCFile(path)
+    assert f.compression == "ZLIB" and f.nrows == 2100
+    md = read.read_metadata(path)
+    assert int(md.compression) == 1
+    for i in range(3):
+        lengths, data = templates[i % len(templates)]
+        assert f.read_stripe(i).column(0).to_pylist() == expected_strings(lengths, data)
+        column = read.read_stripe_column(md, i, read.read_stripe_footer(md, i), 1)
+        assert bytes(column.get_stream(StreamKind.Data)) == data.tobytes()
