@@ -1334,7 +1334,6 @@ struct ShortPlan {
     uint64_t desc;                     // lane k: run k of the batch
     uint32_t rel;                      // ... its first value relative to batch_beg
     bool mine, any_linear, wide;
-    uint64_t base, aux;                // lane k: base and step of a Delta run without packed deltas
     uint64_t b0, b1;                   // stream bytes of the window
     uint4 chunk;                       // lane c: 16-byte chunk c of them, when they are at most 64 chunks
     bool prefetched;
@@ -1403,19 +1402,6 @@ __device__ __forceinline__ int short_plan(const W &wv, uint64_t desc, bool held,
     pl.mine = mine;
     pl.any_linear = __ballot(mine && kind == KIND_DELTA) != 0;
     pl.wide = __ballot(mine && kind != KIND_DELTA && w > 32) != 0;
-    pl.base = 0;
-    pl.aux = 0;
-    if (mine && kind == KIND_DELTA) {
-        // the header scan accepted this header: the parse cannot fail, and reads what it read
-        const uint64_t pos = desc_payload(desc) - desc_header_bytes(desc);
-        ParsedRun r;
-        r.base = 0;
-        r.aux = 0;
-        if (pos < wv.len && parse_run(load_window(wv.s, wv.len, pos), wv.s, wv.len, pos, wv.is_signed, r) == SEG_OK) {
-            pl.base = r.base;
-            pl.aux = r.aux;
-        }
-    }
     // the window's bytes, asked for now: whole aligned 16-byte chunks as stage_bytes reads them
     pl.prefetched = false;
     pl.chunk = make_uint4(0, 0, 0, 0);
@@ -1437,6 +1423,20 @@ __device__ __forceinline__ void short_expand(const W &wv, const ShortPlan &pl) {
     const uint64_t wbase = pl.own_end - WINDOW;
     const uint64_t hi = pl.own_end < pl.batch_end ? pl.own_end : pl.batch_end;
     const uint32_t kind = desc_kind(pl.desc), w = desc_width(pl.desc);
+    // lane k: base and step of a Delta run without packed deltas (parsed here, not while planning:
+    // a plan that is kept across another window's expansion should hold as little as it can)
+    uint64_t base = 0, aux = 0;
+    if (pl.any_linear && pl.mine && kind == KIND_DELTA) {
+        // the header scan accepted this header: the parse cannot fail, and reads what it read
+        const uint64_t pos = desc_payload(pl.desc) - desc_header_bytes(pl.desc);
+        ParsedRun r;
+        r.base = 0;
+        r.aux = 0;
+        if (pos < wv.len && parse_run(load_window(wv.s, wv.len, pos), wv.s, wv.len, pos, wv.is_signed, r) == SEG_OK) {
+            base = r.base;
+            aux = r.aux;
+        }
+    }
     {
         uint64_t origin = pl.b0;
         if (pl.prefetched) {
@@ -1471,20 +1471,20 @@ __device__ __forceinline__ void short_expand(const W &wv, const ShortPlan &pl) {
                                 (w << 22) | (kind << 29);
         const uint32_t lo_w = (uint32_t)(pl.batch_beg - wbase), hi_w = (uint32_t)(hi - wbase);
         if (pl.any_linear) {
-            if (wv.is_signed) expand_window_by_marks<true, true, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
-            else expand_window_by_marks<true, true, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
+            if (wv.is_signed) expand_window_by_marks<true, true, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
+            else expand_window_by_marks<true, true, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
         } else if (pl.wide) {
-            if (wv.is_signed) expand_window_by_marks<true, false, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
-            else expand_window_by_marks<true, false, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
+            if (wv.is_signed) expand_window_by_marks<true, false, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
+            else expand_window_by_marks<true, false, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
         } else {
-            if (wv.is_signed) expand_window_by_marks<false, false, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
-            else expand_window_by_marks<false, false, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, pl.base, pl.aux);
+            if (wv.is_signed) expand_window_by_marks<false, false, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
+            else expand_window_by_marks<false, false, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
         }
     }
     // the windows behind (unless done above): what the last run holds from own_end on; lane i
     // takes values i, i + 64, ...
     const int last = (int)pl.nb - 1;
-    const uint64_t t_base = readlane64(pl.base, last), t_step = readlane64(pl.aux, last);
+    const uint64_t t_base = readlane64(base, last), t_step = readlane64(aux, last);
     for (uint64_t wb = pl.own_end; wb < pl.batch_end && !pl.tail_staged; wb += WINDOW) {
         const uint64_t we = (wb + WINDOW) < pl.batch_end ? wb + WINDOW : pl.batch_end;
         const uint32_t first = (uint32_t)(wb - pl.t_start), end = (uint32_t)(we - pl.t_start);  // indices in the run
