@@ -1333,14 +1333,16 @@ struct ShortPlan {
     uint64_t batch_beg, batch_all, batch_end, own_end;
     uint64_t desc;                     // lane k: run k of the batch
     uint32_t rel;                      // ... its first value relative to batch_beg
-    bool mine, any_linear, wide;
+    bool mine;
+    uint32_t flags;                    // PLAN_* (one scalar register for the four of them)
     uint64_t b0, b1;                   // stream bytes of the window
     uint4 chunk;                       // lane c: 16-byte chunk c of them, when they are at most 64 chunks
-    bool prefetched;
-    bool tail_staged;                  // b1 reaches to the end of the last run's bytes
-    uint64_t t_start, t_pay;           // the batch's last run, which alone may reach past the window
-    uint32_t t_len, t_kind, t_w;
+    uint64_t t_start, t_desc;          // the batch's last run, which alone may reach past the window
 };
+constexpr uint32_t PLAN_ANY_LINEAR = 1;   // some run is a Delta run without packed deltas
+constexpr uint32_t PLAN_WIDE = 2;         // some packed field is wider than 32 bits
+constexpr uint32_t PLAN_PREFETCHED = 4;   // `chunk` holds the window's bytes
+constexpr uint32_t PLAN_TAIL_STAGED = 8;  // b1 reaches to the end of the last run's bytes
 
 constexpr int SHORT_OTHER = 0;    // not a batch of that kind (nothing done: decode_run_batch takes it)
 constexpr int SHORT_NOTHING = 1;  // no run, or every run after the last wanted value
@@ -1372,27 +1374,26 @@ __device__ __forceinline__ int short_plan(const W &wv, uint64_t desc, bool held,
     pl.batch_end = pl.batch_all < wv.num_values ? pl.batch_all : wv.num_values;
     if (batch_beg >= pl.batch_end) return SHORT_NOTHING;  // every run of the batch lies after the last wanted value
     pl.t_start = batch_beg + readlane32(rel, last);
-    pl.t_pay = readlane64(desc_payload(desc), last);
-    pl.t_len = readlane32(len, last);
-    pl.t_kind = readlane32(kind, last);
-    pl.t_w = readlane32(w, last);
+    pl.t_desc = readlane64(desc, last);
+    const uint64_t t_pay = desc_payload(pl.t_desc);
+    const uint32_t t_len = desc_len(pl.t_desc), t_kind = desc_kind(pl.t_desc), t_w = desc_width(pl.t_desc);
     const uint64_t hi = own_end < pl.batch_end ? own_end : pl.batch_end;
     // bytes of the window: from the first run's packed bytes to the last byte that the last run's
     // values in front of `hi` take
-    const uint32_t t_count = hi > pl.t_start ? ((hi - pl.t_start) < pl.t_len ? (uint32_t)(hi - pl.t_start) : pl.t_len) : 0u;
+    const uint32_t t_count = hi > pl.t_start ? ((hi - pl.t_start) < t_len ? (uint32_t)(hi - pl.t_start) : t_len) : 0u;
     uint64_t b0 = readlane64(desc_payload(desc), 0);
-    uint64_t b1 = pl.t_pay + (pl.t_kind == KIND_DIRECT ? ((uint64_t)t_count * pl.t_w + 7) >> 3
-                                                         : (pl.t_kind == KIND_SHORT_REPEAT ? pl.t_w >> 3 : 0u));
+    uint64_t b1 = t_pay + (t_kind == KIND_DIRECT ? ((uint64_t)t_count * t_w + 7) >> 3
+                                                         : (t_kind == KIND_SHORT_REPEAT ? t_w >> 3 : 0u));
     if (b1 > wv.len) b1 = wv.len;  // (never, for a table the header scan made)
     if (b1 < b0 || b1 - b0 + 15 > STAGE_BYTES) return SHORT_OTHER;
     // what the last run holds past the window follows right behind: staged along with the rest
     // when it fits, so that those values cost no memory round trip of their own
-    pl.tail_staged = false;
-    if (pl.batch_end > own_end && pl.t_kind != KIND_DELTA) {
-        uint64_t full = pl.t_pay + (pl.t_kind == KIND_DIRECT ? ((uint64_t)pl.t_len * pl.t_w + 7) >> 3 : pl.t_w >> 3);
+    uint32_t flags = 0;
+    if (pl.batch_end > own_end && t_kind != KIND_DELTA) {
+        uint64_t full = t_pay + (t_kind == KIND_DIRECT ? ((uint64_t)t_len * t_w + 7) >> 3 : t_w >> 3);
         if (full <= wv.len && full >= b1 && full - b0 + 15 <= STAGE_BYTES) {
             b1 = full;
-            pl.tail_staged = true;
+            flags |= PLAN_TAIL_STAGED;
         }
     }
     pl.b0 = b0;
@@ -1400,19 +1401,19 @@ __device__ __forceinline__ int short_plan(const W &wv, uint64_t desc, bool held,
     pl.desc = desc;
     pl.rel = rel;
     pl.mine = mine;
-    pl.any_linear = __ballot(mine && kind == KIND_DELTA) != 0;
-    pl.wide = __ballot(mine && kind != KIND_DELTA && w > 32) != 0;
+    if (__ballot(mine && kind == KIND_DELTA)) flags |= PLAN_ANY_LINEAR;
+    if (__ballot(mine && kind != KIND_DELTA && w > 32)) flags |= PLAN_WIDE;
     // the window's bytes, asked for now: whole aligned 16-byte chunks as stage_bytes reads them
-    pl.prefetched = false;
     pl.chunk = make_uint4(0, 0, 0, 0);
     if (b1 > b0) {
         const uint32_t skew = (uint32_t)((uintptr_t)(wv.s + b0) & 15);
         const uint32_t n16 = (uint32_t)((b1 - b0 + skew + 15) >> 4);
         if (n16 <= 64) {
-            pl.prefetched = true;
+            flags |= PLAN_PREFETCHED;
             if ((uint32_t)lane < n16) pl.chunk = ((const uint4 *)(wv.s + b0 - skew))[lane];
         }
     }
+    pl.flags = flags;
     return SHORT_PLANNED;
 }
 
@@ -1423,10 +1424,14 @@ __device__ __forceinline__ void short_expand(const W &wv, const ShortPlan &pl) {
     const uint64_t wbase = pl.own_end - WINDOW;
     const uint64_t hi = pl.own_end < pl.batch_end ? pl.own_end : pl.batch_end;
     const uint32_t kind = desc_kind(pl.desc), w = desc_width(pl.desc);
+    const bool any_linear = pl.flags & PLAN_ANY_LINEAR, wide = pl.flags & PLAN_WIDE;
+    const bool prefetched = pl.flags & PLAN_PREFETCHED, tail_staged = pl.flags & PLAN_TAIL_STAGED;
+    const uint64_t t_pay = desc_payload(pl.t_desc);
+    const uint32_t t_len = desc_len(pl.t_desc), t_kind = desc_kind(pl.t_desc), t_w = desc_width(pl.t_desc);
     // lane k: base and step of a Delta run without packed deltas (parsed here, not while planning:
     // a plan that is kept across another window's expansion should hold as little as it can)
     uint64_t base = 0, aux = 0;
-    if (pl.any_linear && pl.mine && kind == KIND_DELTA) {
+    if (any_linear && pl.mine && kind == KIND_DELTA) {
         // the header scan accepted this header: the parse cannot fail, and reads what it read
         const uint64_t pos = desc_payload(pl.desc) - desc_header_bytes(pl.desc);
         ParsedRun r;
@@ -1439,7 +1444,7 @@ __device__ __forceinline__ void short_expand(const W &wv, const ShortPlan &pl) {
     }
     {
         uint64_t origin = pl.b0;
-        if (pl.prefetched) {
+        if (prefetched) {
             const uint32_t skew = (uint32_t)((uintptr_t)(wv.s + pl.b0) & 15);
             uint4 v = pl.chunk;  // (chunks past the span are zero and land inside the slice)
             v.x = __builtin_bswap32(v.x);
@@ -1453,15 +1458,15 @@ __device__ __forceinline__ void short_expand(const W &wv, const ShortPlan &pl) {
         } else if (pl.b1 > pl.b0) {
             origin = stage_bytes(wv, pl.b0, pl.b1);
         }
-        if (pl.tail_staged) {
+        if (tail_staged) {
             // the last run's values from own_end on, out of the bytes just staged (before the
             // window's own expansion takes the slice for its output tile); lane i takes values
             // i, i + 64, ...
             const uint32_t first = (uint32_t)(pl.own_end - pl.t_start);
             const uint32_t end = (uint32_t)(pl.batch_end - pl.t_start);
-            const uint32_t bit0 = (uint32_t)((pl.t_pay - origin) << 3);
+            const uint32_t bit0 = (uint32_t)((t_pay - origin) << 3);
             for (uint32_t idx = first + (uint32_t)lane; idx < end; idx += 64) {
-                const uint64_t m = lds_bits64(wv.lds, bit0 + (pl.t_kind == KIND_DIRECT ? idx * pl.t_w : 0u), pl.t_w);
+                const uint64_t m = lds_bits64(wv.lds, bit0 + (t_kind == KIND_DIRECT ? idx * t_w : 0u), t_w);
                 stream_store1(wv.out + pl.t_start + idx, wv.is_signed ? zigzag(m) : m);
             }
         }
@@ -1470,10 +1475,10 @@ __device__ __forceinline__ void short_expand(const W &wv, const ShortPlan &pl) {
                                 ((((uint32_t)desc_payload(pl.desc) - (uint32_t)origin) & 8191u) << 9) |
                                 (w << 22) | (kind << 29);
         const uint32_t lo_w = (uint32_t)(pl.batch_beg - wbase), hi_w = (uint32_t)(hi - wbase);
-        if (pl.any_linear) {
+        if (any_linear) {
             if (wv.is_signed) expand_window_by_marks<true, true, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
             else expand_window_by_marks<true, true, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
-        } else if (pl.wide) {
+        } else if (wide) {
             if (wv.is_signed) expand_window_by_marks<true, false, true>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
             else expand_window_by_marks<true, false, false>(wv, wbase, lo_w, hi_w, my_ws, my_rec, base, aux);
         } else {
@@ -1485,20 +1490,20 @@ __device__ __forceinline__ void short_expand(const W &wv, const ShortPlan &pl) {
     // takes values i, i + 64, ...
     const int last = (int)pl.nb - 1;
     const uint64_t t_base = readlane64(base, last), t_step = readlane64(aux, last);
-    for (uint64_t wb = pl.own_end; wb < pl.batch_end && !pl.tail_staged; wb += WINDOW) {
+    for (uint64_t wb = pl.own_end; wb < pl.batch_end && !tail_staged; wb += WINDOW) {
         const uint64_t we = (wb + WINDOW) < pl.batch_end ? wb + WINDOW : pl.batch_end;
         const uint32_t first = (uint32_t)(wb - pl.t_start), end = (uint32_t)(we - pl.t_start);  // indices in the run
         uint32_t bit0 = 0;  // bit in the slice of the run's packed field 0 (modulo 2^32)
-        if (pl.t_kind != KIND_DELTA) {
-            const uint64_t f0 = pl.t_kind == KIND_DIRECT ? ((uint64_t)first * pl.t_w) >> 3 : 0u;
-            const uint64_t f1 = pl.t_kind == KIND_DIRECT ? ((uint64_t)end * pl.t_w + 7) >> 3 : pl.t_w >> 3;
-            const uint64_t origin = stage_bytes(wv, pl.t_pay + f0, pl.t_pay + f1);
-            bit0 = (uint32_t)((pl.t_pay - origin) << 3);
+        if (t_kind != KIND_DELTA) {
+            const uint64_t f0 = t_kind == KIND_DIRECT ? ((uint64_t)first * t_w) >> 3 : 0u;
+            const uint64_t f1 = t_kind == KIND_DIRECT ? ((uint64_t)end * t_w + 7) >> 3 : t_w >> 3;
+            const uint64_t origin = stage_bytes(wv, t_pay + f0, t_pay + f1);
+            bit0 = (uint32_t)((t_pay - origin) << 3);
         }
         for (uint32_t idx = first + (uint32_t)lane; idx < end; idx += 64) {
             uint64_t val = t_base + (uint64_t)idx * t_step;  // Delta without packed deltas
-            if (pl.t_kind != KIND_DELTA) {
-                const uint64_t m = lds_bits64(wv.lds, bit0 + (pl.t_kind == KIND_DIRECT ? idx * pl.t_w : 0u), pl.t_w);
+            if (t_kind != KIND_DELTA) {
+                const uint64_t m = lds_bits64(wv.lds, bit0 + (t_kind == KIND_DIRECT ? idx * t_w : 0u), t_w);
                 val = wv.is_signed ? zigzag(m) : m;
             }
             stream_store1(wv.out + pl.t_start + idx, val);
