@@ -111,9 +111,13 @@ float orcd_ctx_phase_ms(orcd_ctx *ctx, int phase);
 /* Which way the most recent orcd_rlev2_decode call on this context went: ORCD_PATH_GENERAL (header
  * scan, run table, value expansion) or ORCD_PATH_STRIDED (a column whose every 512 values are one
  * Direct run, with equally many equal-sized runs between two entry points, is expanded by a single
- * launch that checks each run header as it goes; the library tries this first and falls back).
+ * launch that checks each run header as it goes) or ORCD_PATH_PLANNED (a column whose every 512
+ * values are one run of any kind -- full Delta runs of sorted keys, say -- with equally many runs
+ * between two entry points: one launch finds and verifies every run header, the value expansion
+ * follows it without prefix sums or a wait in between).  The library tries the one that worked
+ * for the context's last column first, then the other, and falls back to the general path.
  * The results are the same either way; this is for benchmarks and profiles. */
-enum { ORCD_PATH_GENERAL = 0, ORCD_PATH_STRIDED = 1 };
+enum { ORCD_PATH_GENERAL = 0, ORCD_PATH_STRIDED = 1, ORCD_PATH_PLANNED = 2 };
 int orcd_ctx_last_path(orcd_ctx *ctx);
 /* Text of the last HIP runtime error seen by this context (after ORCD_HIP_ERROR). */
 const char *orcd_ctx_last_hip_error(orcd_ctx *ctx);

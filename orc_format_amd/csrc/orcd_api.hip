@@ -256,6 +256,7 @@ struct orcd_ctx {
     // Speculative decode of regular columns (try_strided): which way the last RLE v2 call went
     // (ORCD_PATH_*), and how many eligible calls skip the attempt after it failed twice in a row.
     int last_path = 0;
+    int spec_pref = ORCD_PATH_STRIDED;  // the speculative path that worked last, tried first
     uint32_t spec_fail_streak = 0, spec_skip = 0;
     bool spec_flag_clean = false;  // the device word of SLOT_SPEC_FLAG is known to be zero
 };
@@ -670,63 +671,142 @@ int rlev2_table_with(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t nu
 constexpr size_t SPEC_MIN_VALUES = 8 * WINDOW;
 constexpr uint32_t SPEC_BACKOFF = 16;
 
-// flag_word (nullable): the device word to use instead of the context's own, zero on entry.
-int try_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
-                const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done,
-                uint32_t *flag_word = nullptr) {
-    *done = false;
+// Whether a call is for the speculative paths at all, and the count-down after failed attempts.
+bool spec_gate(orcd_ctx *c, size_t len, size_t num_values, size_t n_entries) {
     // ORCD_NO_SPECULATION=1 in the environment: always the general path (for profiles of it)
     static const bool disabled = [] {
         const char *e = getenv("ORCD_NO_SPECULATION");
         return e && *e && *e != '0';
     }();
-    if (disabled) return ORCD_OK;
-    if (num_values < SPEC_MIN_VALUES || (((uintptr_t)d_out) & 15) || n_entries > 0xFFFFFFFFull) return ORCD_OK;
+    if (disabled) return false;
+    if (num_values < SPEC_MIN_VALUES || n_entries > 0xFFFFFFFFull) return false;
     const uint64_t n_win = (num_values + WINDOW - 1) >> WINDOW_SHIFT;
     const uint64_t n_seg = n_entries ? n_entries : 1;
-    if (n_win > 0xFFFFFFFFull || n_seg > n_win || len < n_win * 3) return ORCD_OK;
+    if (n_win > 0xFFFFFFFFull || n_seg > n_win || len < n_win * 3) return false;
     if (c->spec_skip) {
         c->spec_skip--;
-        return ORCD_OK;
+        return false;
     }
-    // the context's flag word is zero between launches: the publishing kernel leaves it so
-    void *flag = flag_word;
-    if (!flag) {
-        ORCD_TRY(ensure(c, SLOT_SPEC_FLAG, 256, &flag));
-        if (!c->spec_flag_clean) {
-            HIP_TRY(c, hipMemsetAsync(flag, 0, 256, c->stream));
-            c->spec_flag_clean = true;
-        }
-    }
-    const uint32_t stamp = next_stamp(c);
-    HIP_TRY(c, launch_rlev2_strided_values(c->stream, d_stream, len, n_entries ? d_entries : nullptr,
-                                           (uint32_t)n_seg, (uint32_t)n_win, num_values, is_signed, d_out,
-                                           (uint32_t *)flag, c->h_totals, stamp));
-    mark(c, 3);  // (phases 1 and 2, header count and run table, did not run)
-    const int rc = wait_totals_stamp(c, stamp, nullptr);
-    if (rc != ORCD_OK) {
-        c->spec_flag_clean = false;
-        return rc;
-    }
-    if (c->h_totals->error == 0) {
-        *done = true;
+    return true;
+}
+
+void spec_account(orcd_ctx *c, bool done) {
+    if (done) {
         c->spec_fail_streak = 0;
     } else if (++c->spec_fail_streak >= 2) {
         // 16 calls, then 32, 64, ... up to 1024 while the attempts keep failing
         const uint32_t doublings = std::min<uint32_t>(c->spec_fail_streak - 2, 6);
         c->spec_skip = SPEC_BACKOFF << doublings;
     }
+}
+
+// the context's flag word is zero between launches: the publishing kernel leaves it so
+int spec_flag(orcd_ctx *c, uint32_t **flag) {
+    void *f;
+    ORCD_TRY(ensure(c, SLOT_SPEC_FLAG, 256, &f));
+    if (!c->spec_flag_clean) {
+        HIP_TRY(c, hipMemsetAsync(f, 0, 256, c->stream));
+        c->spec_flag_clean = true;
+    }
+    *flag = (uint32_t *)f;
+    return ORCD_OK;
+}
+
+int spec_verdict(orcd_ctx *c, uint32_t stamp, bool *done) {
+    const int rc = wait_totals_stamp(c, stamp, nullptr);
+    if (rc != ORCD_OK) {
+        c->spec_flag_clean = false;
+        return rc;
+    }
+    *done = c->h_totals->error == 0;
+    return ORCD_OK;
+}
+
+// flag_word (nullable): the device word to use instead of the context's own, zero on entry.
+int attempt_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
+                    const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done,
+                    uint32_t *flag_word = nullptr) {
+    *done = false;
+    if (((uintptr_t)d_out) & 15) return ORCD_OK;
+    const uint64_t n_win = (num_values + WINDOW - 1) >> WINDOW_SHIFT;
+    const uint64_t n_seg = n_entries ? n_entries : 1;
+    uint32_t *flag = flag_word;
+    if (!flag) ORCD_TRY(spec_flag(c, &flag));
+    const uint32_t stamp = next_stamp(c);
+    HIP_TRY(c, launch_rlev2_strided_values(c->stream, d_stream, len, n_entries ? d_entries : nullptr,
+                                           (uint32_t)n_seg, (uint32_t)n_win, num_values, is_signed, d_out,
+                                           flag, c->h_totals, stamp));
+    mark(c, 3);  // (phases 1 and 2, header count and run table, did not run)
+    return spec_verdict(c, stamp, done);
+}
+
+// The column of full runs of any kind (see rlev2_regular_plan_kernel): the plan of the windows and
+// the value kernel behind it in one go, no prefix sums and no wait in between.
+int attempt_planned(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
+                    const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done) {
+    *done = false;
+    const uint64_t n_win = (num_values + WINDOW - 1) >> WINDOW_SHIFT;
+    if (n_entries < 2 || n_entries > n_win) return ORCD_OK;
+    uint32_t *flag;
+    ORCD_TRY(spec_flag(c, &flag));
+    void *group_runs;
+    ORCD_TRY(ensure(c, SLOT_GROUP_RUNS, (size_t)(n_win + 1) * sizeof(RunEntry), &group_runs));
+    bool eligible = false;
+    HIP_TRY(c, launch_rlev2_regular_plan(c->stream, d_stream, len, d_entries, (uint32_t)n_entries, (uint32_t)n_win,
+                                         num_values, is_signed, (RunEntry *)group_runs, flag, &eligible));
+    if (!eligible) return ORCD_OK;
+    mark(c, 1);
+    mark(c, 2);
+    Rlev2Table t;
+    t.stream = d_stream;
+    t.len = len;
+    t.runs = nullptr;  // every window is one run: the table of the shared windows is never looked at
+    t.group_first = nullptr;
+    t.group_run = (const RunEntry *)group_runs;
+    t.n_groups = (uint32_t)n_win;
+    t.n_runs = 0;
+    t.num_values = num_values;
+    t.is_signed = is_signed;
+    HIP_TRY(c, launch_rlev2_values(c->stream, t, d_out, flag));
+    mark(c, 3);
+    const uint32_t stamp = next_stamp(c);
+    HIP_TRY(c, launch_spec_publish(c->stream, flag, c->h_totals, stamp));
+    return spec_verdict(c, stamp, done);
+}
+
+int try_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
+                const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done,
+                uint32_t *flag_word = nullptr) {
+    *done = false;
+    if ((((uintptr_t)d_out) & 15) || !spec_gate(c, len, num_values, n_entries)) return ORCD_OK;
+    ORCD_TRY(attempt_strided(c, d_stream, len, num_values, d_entries, n_entries, is_signed, d_out, done, flag_word));
+    spec_account(c, *done);
     return ORCD_OK;
 }
 
 int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
                  const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out) {
-    bool done = false;
     c->last_path = ORCD_PATH_GENERAL;
-    ORCD_TRY(try_strided(c, d_stream, len, num_values, d_entries, n_entries, is_signed, d_out, &done));
-    if (done) {
-        c->last_path = ORCD_PATH_STRIDED;
-        return ORCD_OK;
+    if (spec_gate(c, len, num_values, n_entries)) {
+        // the way that worked last time first, then the other
+        bool done = false;
+        const int first = c->spec_pref;
+        for (int attempt = 0; attempt < 2 && !done; attempt++) {
+            const int way = attempt == 0 ? first
+                                         : (first == ORCD_PATH_STRIDED ? ORCD_PATH_PLANNED : ORCD_PATH_STRIDED);
+            if (way == ORCD_PATH_STRIDED)
+                ORCD_TRY(attempt_strided(c, d_stream, len, num_values, d_entries, n_entries, is_signed, d_out, &done));
+            else
+                ORCD_TRY(attempt_planned(c, d_stream, len, num_values, d_entries, n_entries, is_signed, d_out, &done));
+            if (done) {
+                c->spec_pref = c->last_path = way;
+                // equal-sized Direct runs all through: the strided kernel needs no plan for such a
+                // column (the plan noted it beside its verdict)
+                if (way == ORCD_PATH_PLANNED && c->h_totals->error_seg == 0) c->spec_pref = ORCD_PATH_STRIDED;
+            }
+        }
+        spec_account(c, done);
+        if (done) return ORCD_OK;
     }
     Rlev2Table t;
     ORCD_TRY(rlev2_table(c, d_stream, len, num_values, d_entries, n_entries, is_signed, &t));

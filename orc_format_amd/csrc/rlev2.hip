@@ -1754,6 +1754,13 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
     constexpr bool PAIRED = SHORT && MODE == MODE_VALUES;  // a wavefront takes two neighbouring windows
     const uint32_t g = (wg * VAL_WAVES + wave) * (PAIRED ? 2 : 1);
     if (g >= n_groups) return;  // whole wavefront leaves; no workgroup barrier is used below
+    // MODE_VALUES behind a speculative plan of the column (rlev2_regular_plan_kernel): a raised
+    // flag means the tables were not all written, and nothing may be decoded from them
+    // (the load is only issued here; the entry's loads below go out with it)
+    uint32_t aborted = 0;
+    // (a plain load: the word is final before this kernel starts, every wavefront reads it, and
+    // loads that bypass the caches would all queue at the one memory channel that holds it)
+    if (MODE == MODE_VALUES && flags != nullptr) aborted = *flags;
     __shared__ uint32_t marks[VAL_WAVES][WINDOW / 32];
     WaveOf<MODE> wv;
     wv.s = s;
@@ -1788,6 +1795,7 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
         const bool two = g + 1 < n_groups;
         const RunEntry *e0 = group_run + g, *e1 = group_run + (two ? g + 1 : g);
         const uint64_t d0 = readfirstlane64(e0->desc), d1 = readfirstlane64(e1->desc);
+        if (__builtin_amdgcn_readfirstlane(aborted)) return;
         const bool multi0 = !(d0 & DESC_SINGLE), multi1 = two && !(d1 & DESC_SINGLE);
         uint64_t r0 = multi0 ? readfirstlane64(e0->base) : n_runs, r1 = multi1 ? readfirstlane64(e1->base) : n_runs;
         if (r0 > n_runs) r0 = n_runs;
@@ -1830,6 +1838,7 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
     // faster on single-run columns and slower on columns of short runs.)
     const RunEntry *e = group_run + g;  // wave-uniform address
     const uint64_t desc = readfirstlane64(e->desc);
+    if (__builtin_amdgcn_readfirstlane(aborted)) return;
     if (desc & DESC_SINGLE) {
         decode_single_run(wv, desc, readfirstlane64(e->out_off), readfirstlane64(e->base),
                           readfirstlane64(e->aux));
@@ -1967,8 +1976,10 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel
 __global__ void spec_publish_kernel(uint32_t *__restrict__ flag, ScanTotals *host_totals, uint32_t stamp) {
     if (threadIdx.x || blockIdx.x) return;
     volatile ScanTotals *h = host_totals;
-    h->error = *flag;
-    *flag = 0;
+    h->error = flag[0];
+    h->error_seg = flag[1];  // (what rlev2_regular_plan_kernel noted beside its verdict)
+    flag[0] = 0;
+    flag[1] = 0;
     __threadfence_system();
     h->pad = stamp;
 }
@@ -1981,6 +1992,205 @@ hipError_t launch_rlev2_strided_values(hipStream_t st, const uint8_t *stream, ui
     const uint32_t blocks = (n_win + VAL_WAVES - 1) / VAL_WAVES;
     rlev2_strided_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, entries, n_seg, n_win,
                                                                   num_values, is_signed, out, flag);
+    spec_publish_kernel<<<1, 64, 0, st>>>(flag, host_totals, stamp);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 + K2 in one pass, without prefix sums, for the column whose every window of 512 values is one
+// run of 512 values of any kind (sorted keys and timestamps come as full Delta runs) with
+// `runs_per_seg` runs between two entry points.  Run g is then window g, its place in the output is
+// 512 g, and the only unknown is where its header lies: run sizes differ by the bytes of their
+// varints, so positions are not arithmetic as they are for Direct runs.  One lane per run *guesses*:
+// it interpolates between the entry points on both sides of its segment and looks, in the 64 bytes
+// around that offset, for the two bytes every header of a 512-value run of the segment's kind and
+// width starts with.  One hit is the guess; none or several, and the lane walks the chain from
+// the segment's entry point instead (at most 64 hops, else the column is not for this path).
+// Guesses prove nothing; the links do.  Window g's run must hold 512 values and end exactly where
+// lane g + 1 says run g + 1 starts, the first run of a segment starts at its entry point, and so,
+// by induction over g, every position is the one a walk of the header chain arrives at
+// (rle_v2.rs:441-461, 480-514).  Any link that does not hold raises *flag: the value kernel
+// launched behind this one then does nothing and the caller decodes the stream the general way.
+// A wavefront takes 63 windows; its last lane computes the first window of the next wavefront a
+// second time (the choice is a function of the stream alone) so that every link is checked.
+// ---------------------------------------------------------------------------------------------
+
+// 0x80 in every byte of v that is zero (exact: no carries between bytes)
+__device__ __forceinline__ uint64_t zero_bytes(uint64_t v) {
+    const uint64_t m = 0x7F7F7F7F7F7F7F7Full;
+    return ~(((v & m) + m) | v | m);
+}
+
+constexpr uint32_t PLAN_MAX_WALK = 64;
+
+__global__ __launch_bounds__(256) void rlev2_regular_plan_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries, uint32_t n_seg,
+    uint32_t n_win, uint32_t r_lo, uint32_t r_hi, uint64_t num_values, int is_signed,
+    RunEntry *__restrict__ group_run, uint32_t *__restrict__ flag) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint64_t g64 = wave_id * 63 + lane;
+    if (wave_id * 63 >= n_win) return;  // whole wavefront
+    if (__builtin_amdgcn_readfirstlane(*(const volatile uint32_t *)flag)) return;
+    const bool live = g64 < n_win;
+    const uint32_t g = live ? (uint32_t)g64 : n_win - 1;
+    bool bad = false;
+    // Runs per segment: the counts of windows and entry points leave r_lo .. r_hi (one value for
+    // any column of many segments); among several, the one nearest to what the stream's average
+    // bytes per window make of the first segment.  A wrong choice fails the links.
+    uint32_t runs_per_seg = r_lo;
+    if (r_lo != r_hi) {
+        const double est = (double)entries[1] * (double)n_win / (double)(len ? len : 1) + 0.5;
+        runs_per_seg = est < (double)r_lo ? r_lo : (est > (double)r_hi ? r_hi : (uint32_t)est);
+        runs_per_seg = __builtin_amdgcn_readfirstlane(runs_per_seg);
+    }
+    uint32_t seg = g / runs_per_seg;
+    if (seg >= n_seg) seg = n_seg - 1;  // the last segment holds whatever is left
+    const uint32_t k = g - seg * runs_per_seg;
+    const uint64_t e0 = seg ? entries[seg] : 0;
+    if (e0 >= len) bad = true;
+    // Where to look: 64 stream bytes from a 16-byte boundary, fetched with four 16-byte loads.
+    // The first run of a segment sits at the entry point; any other is expected at the offset
+    // interpolated between this segment's entry point and the next one's (the last segment has
+    // none after it and borrows the spacing of the segment before) and searched for from 16 bytes
+    // before that on.  Headers that start in the block's first 48 bytes can be parsed out of it.
+    const bool last_seg = seg + 1 == n_seg;
+    const uint64_t ea = last_seg ? (seg > 1 ? entries[seg - 1] : 0) : e0;
+    const uint64_t eb = last_seg ? e0 : entries[seg + 1];
+    uint64_t from = e0;
+    if (k != 0) {
+        const double span = eb > ea ? (double)(eb - ea) : 0.0;
+        const uint64_t mid = e0 + (uint64_t)(span * (double)k * __builtin_amdgcn_rcp((double)runs_per_seg));
+        from = mid > e0 + 16 ? mid - 16 : e0 + 1;
+    }
+    if (from >= len) from = bad ? 0 : e0;
+    const uintptr_t a0 = (uintptr_t)(s + from) & ~(uintptr_t)15;
+    const uintptr_t end = (uintptr_t)(s + len);
+    const uint4 *blk = (const uint4 *)a0;
+    uint64_t q[8];
+    {
+        // a chunk at or past the end is replaced by a re-read of the first (select on the address)
+        uint4 c[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) c[i] = *((a0 + 16 * i < end) ? blk + i : blk);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            q[2 * i] = ((uint64_t)c[i].y << 32) | c[i].x;
+            q[2 * i + 1] = ((uint64_t)c[i].w << 32) | c[i].z;
+        }
+    }
+    uint32_t at = (uint32_t)((uintptr_t)(s + from) - a0);  // k == 0: the entry point itself
+    bool found = k == 0;
+    if (k != 0 && !bad) {
+        // the two bytes a run of 512 values of this segment's kind and width starts with
+        const uint64_t first = 0x0101010101010101ull * (uint64_t)s[e0];
+        uint32_t hits = 0;
+        uint64_t ff_next = zero_bytes(~q[0]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const uint64_t is_h0 = zero_bytes(q[i] ^ first);
+            const uint64_t ff = ff_next;
+            ff_next = zero_bytes(~q[i + 1]);
+            const uint64_t m = is_h0 & ((ff >> 8) | (ff_next << 56));  // byte j is h0 and byte j + 1 is 0xFF
+            if (m) {
+                hits += __builtin_popcountll(m);
+                at = 8 * i + (__builtin_ctzll(m) >> 3);
+            }
+        }
+        // (chunks read in place of ones past the end may add hits that are not there: more than
+        // one hit, or one outside the stream, only sends the lane on the walk)
+        const uint64_t cand = (uint64_t)(a0 - (uintptr_t)s) + at;
+        found = hits == 1 && cand > e0 && cand < len && len - cand >= 2;
+    }
+    uint64_t pos = (uint64_t)(a0 - (uintptr_t)s) + at;
+    Window16 w;
+    {
+        // the 16 bytes at `at` out of the block (at <= 47)
+        const uint32_t wi = at >> 3, sh = (at & 7) * 8;
+        uint64_t x0 = q[0], x1 = q[1], x2 = q[2];
+#pragma unroll
+        for (int i = 1; i < 6; i++)
+            if (wi == (uint32_t)i) {
+                x0 = q[i];
+                x1 = q[i + 1];
+                x2 = q[i + 2];
+            }
+        w.lo = sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0;
+        w.hi = sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1;
+    }
+    if (!found && !bad) {
+        // no guess: the chain from the entry point, a run at a time
+        if (k > PLAN_MAX_WALK) bad = true;
+        pos = e0;
+        for (uint32_t j = 0; j < k && !bad; j++) {
+            ParsedRun hop;
+            if (pos >= len || parse_run(load_window(s, len, pos), s, len, pos, is_signed, hop) != SEG_OK)
+                bad = true;
+            else
+                pos = hop.run_end;
+        }
+        if (!bad && pos < len) w = load_window(s, len, pos);
+    }
+    ParsedRun r;
+    r.run_end = 0;
+    r.base = 0;
+    r.aux = 0;
+    r.kind = 0;
+    uint64_t desc = 0;
+    if (!bad) {
+        if (pos >= len || parse_run(w, s, len, pos, is_signed, r) != SEG_OK) {
+            bad = true;
+        } else {
+            desc = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes) | DESC_SINGLE;
+            const uint64_t wbase = (uint64_t)g << WINDOW_SHIFT;
+            if (g + 1 == n_win) {
+                // the column's last run: any length that holds the values still wanted
+                if (wbase >= num_values || (uint64_t)r.len < num_values - wbase) bad = true;
+            } else if (r.len != WINDOW) {
+                bad = true;
+            }
+        }
+    }
+    // the link: this run ends where the next lane's begins (lanes past the last window mirror it
+    // and are not looked at)
+    const uint64_t next_pos = shfl64(pos, (int)(lane < 63 ? lane + 1 : 63));
+    const bool linked = live && lane < 63 && g + 1 < n_win && !bad;
+    if (linked && r.run_end != next_pos) bad = true;
+    if (live && bad) atomicOr(flag, 1u);
+    // flag[1]: some run is not a Direct run, or not of its successor's size -- a column that
+    // leaves it zero is one the strided kernel decodes without this pass
+    const uint64_t size = r.run_end - pos;
+    const uint64_t next_size = shfl64(size, (int)(lane < 63 ? lane + 1 : 63));
+    if (linked && (r.kind != KIND_DIRECT || (g + 2 < n_win && size != next_size))) {
+        if (__builtin_amdgcn_readfirstlane(*(const volatile uint32_t *)(flag + 1)) == 0) atomicOr(flag + 1, 1u);
+    }
+    if (live && lane < 63 && !bad) {
+        RunEntry e;
+        e.desc = desc;
+        e.out_off = (uint64_t)g << WINDOW_SHIFT;
+        e.base = r.base;
+        e.aux = r.aux;
+        group_run[g] = e;
+    }
+}
+
+hipError_t launch_rlev2_regular_plan(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                     const uint64_t *entries, uint32_t n_seg, uint32_t n_win,
+                                     uint64_t num_values, int is_signed, RunEntry *group_run,
+                                     uint32_t *flag, bool *eligible) {
+    *eligible = false;
+    if (n_win == 0 || n_seg < 2 || n_seg > n_win || !entries) return hipSuccess;
+    // n_win = (n_seg - 1) * runs_per_seg + (1 .. runs_per_seg windows of the last segment)
+    const uint32_t r_lo = (n_win + n_seg - 1) / n_seg, r_hi = (n_win - 1) / (n_seg - 1);
+    if (r_lo > r_hi) return hipSuccess;
+    *eligible = true;
+    const uint64_t waves = ((uint64_t)n_win + 62) / 63;
+    rlev2_regular_plan_kernel<<<(uint32_t)((waves + 3) / 4), 256, 0, st>>>(
+        stream, len, entries, n_seg, n_win, r_lo, r_hi, num_values, is_signed, group_run, flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_spec_publish(hipStream_t st, uint32_t *flag, ScanTotals *host_totals, uint32_t stamp) {
     spec_publish_kernel<<<1, 64, 0, st>>>(flag, host_totals, stamp);
     return hipGetLastError();
 }
@@ -2128,8 +2338,9 @@ hipError_t launch_rlev2_resync(hipStream_t st, const uint8_t *stream, uint64_t l
     return hipGetLastError();
 }
 
-hipError_t launch_rlev2_values(hipStream_t st, const Rlev2Table &t, int64_t *out) {
-    return launch_values_mode<MODE_VALUES>(st, t, out, nullptr, nullptr);
+hipError_t launch_rlev2_values(hipStream_t st, const Rlev2Table &t, int64_t *out,
+                               const uint32_t *abort_flag) {
+    return launch_values_mode<MODE_VALUES>(st, t, out, nullptr, const_cast<uint32_t *>(abort_flag));
 }
 
 hipError_t launch_rlev2_group_sums(hipStream_t st, const Rlev2Table &t, uint64_t *group_sums,

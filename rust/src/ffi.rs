@@ -45,6 +45,7 @@ pub const ORCD_NOALLOC_MAX_ENTRIES: usize = 65536;
 pub const ORCD_NOALLOC_MAX_RUNS: usize = 524288;
 pub const ORCD_PATH_GENERAL: c_int = 0;
 pub const ORCD_PATH_STRIDED: c_int = 1;
+pub const ORCD_PATH_PLANNED: c_int = 2;
 
 // stream kinds (src/proto.rs:127-136) and column encodings (src/proto.rs:149-154)
 pub const ORCD_STREAM_PRESENT: c_int = 0;

@@ -88,7 +88,8 @@ def test_strided_last_run_of_another_kind(ctx, oracle):
 
 def test_one_run_breaks_the_stride(ctx, oracle):
     """A column that is regular but for one run in the middle -- another width, hence another size --
-    is decoded the general way, with the same answer."""
+    is not for the strided path: the plan-and-expand path takes it when there are entry points to
+    plan between, the general path otherwise, with the same answer."""
     rng = np.random.default_rng(7)
     parts, vals, starts, pos = [], [], [], 0
     for r in range(60):
@@ -100,7 +101,7 @@ def test_one_run_breaks_the_stride(ctx, oracle):
         parts.append(b)
         vals.append(v)
     stream, vals = b"".join(parts), np.concatenate(vals)
-    check(ctx, oracle, stream, vals.size, True, np.array(starts[::20], dtype=np.uint64), PATH_GENERAL, vals)
+    check(ctx, oracle, stream, vals.size, True, np.array(starts[::20], dtype=np.uint64), 2, vals)
     check(ctx, oracle, stream, vals.size, True, None, PATH_GENERAL, vals)
 
 
@@ -122,7 +123,9 @@ def test_a_short_run_in_the_middle(ctx, oracle):
     check(ctx, oracle, stream, vals.size, False, np.array(starts[::10], dtype=np.uint64), PATH_GENERAL, vals)
 
 
-def test_delta_column_takes_the_general_path(ctx, oracle):
+def test_delta_column_is_not_for_the_strided_path(ctx, oracle):
+    """Full Delta runs have no common size: the strided attempt fails and the plan-and-expand path
+    (tests/test_gpu_planned.py) takes the column."""
     rng = np.random.default_rng(9)
     parts, vals, starts, pos, t = [], [], [], 0, 1_600_000_000_000
     for r in range(40):
@@ -135,7 +138,7 @@ def test_delta_column_takes_the_general_path(ctx, oracle):
         parts.append(b)
         vals.append(v)
     stream, vals = b"".join(parts), np.concatenate(vals)
-    check(ctx, oracle, stream, vals.size, True, np.array(starts[::20], dtype=np.uint64), PATH_GENERAL, vals)
+    check(ctx, oracle, stream, vals.size, True, np.array(starts[::20], dtype=np.uint64), 2, vals)
 
 
 def test_entry_points_that_are_not_evenly_spaced(ctx, oracle):
@@ -186,14 +189,15 @@ def test_back_off_and_recovery(ctx, oracle):
 
 
 def test_device_pointers_full_window_alignment(ctx, oracle):
-    """Device-pointer call; an output that is not 16-byte aligned takes the general path."""
+    """Device-pointer call; an output that is not 16-byte aligned is not for the strided kernel
+    (the plan-and-expand path, which has no such condition, takes the column)."""
     import torch
     rng = np.random.default_rng(14)
     stream, vals, entries, _ = direct_column(rng, 64, 17, True)
     d_stream = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda()
     d_entries = torch.from_numpy(entries.view(np.int64).copy()).cuda()
     buf = torch.zeros(vals.size + 2, dtype=torch.int64, device="cuda")
-    for shift, want in ((0, PATH_STRIDED), (1, PATH_GENERAL)):
+    for shift, want in ((0, PATH_STRIDED), (1, 2)):
         out = buf[shift:shift + vals.size]
         out.zero_()
         ctx.rlev2_device(d_stream.data_ptr(), d_stream.numel(), vals.size, True, out.data_ptr(),
