@@ -746,15 +746,14 @@ int attempt_planned(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
                     const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done) {
     *done = false;
     const uint64_t n_win = (num_values + WINDOW - 1) >> WINDOW_SHIFT;
-    if (n_entries < 2 || n_entries > n_win) return ORCD_OK;
+    uint32_t r_lo, r_hi;
+    if (n_entries < 2 || !rlev2_regular_plan_shape((uint32_t)n_entries, (uint32_t)n_win, &r_lo, &r_hi)) return ORCD_OK;
     uint32_t *flag;
     ORCD_TRY(spec_flag(c, &flag));
     void *group_runs;
     ORCD_TRY(ensure(c, SLOT_GROUP_RUNS, (size_t)(n_win + 1) * sizeof(RunEntry), &group_runs));
-    bool eligible = false;
     HIP_TRY(c, launch_rlev2_regular_plan(c->stream, d_stream, len, d_entries, (uint32_t)n_entries, (uint32_t)n_win,
-                                         num_values, is_signed, (RunEntry *)group_runs, flag, &eligible));
-    if (!eligible) return ORCD_OK;
+                                         num_values, is_signed, (RunEntry *)group_runs, flag));
     mark(c, 1);
     mark(c, 2);
     Rlev2Table t;

@@ -180,12 +180,14 @@ hipError_t launch_rlev2_values(hipStream_t st, const Rlev2Table &t, int64_t *out
                                const uint32_t *abort_flag = nullptr);
 // The run of every window for the column whose windows of 512 values are one run of 512 values
 // each (any kind), equally many of them between two entry points (see rlev2_regular_plan_kernel):
-// group_run[0 .. n_win), or *flag raised when the column is not like that.  *eligible: whether the
-// counts of windows and entry points allow such a column at all (nothing is launched otherwise).
+// group_run[0 .. n_win), or *flag raised when the column is not like that.
+// rlev2_regular_plan_shape: whether the counts of windows and entry points allow such a column at
+// all, and the runs per segment they leave possible (the kernel picks among several).
+bool rlev2_regular_plan_shape(uint32_t n_seg, uint32_t n_win, uint32_t *r_lo, uint32_t *r_hi);
 hipError_t launch_rlev2_regular_plan(hipStream_t st, const uint8_t *stream, uint64_t len,
                                      const uint64_t *entries, uint32_t n_seg, uint32_t n_win,
                                      uint64_t num_values, int is_signed, RunEntry *group_run,
-                                     uint32_t *flag, bool *eligible);
+                                     uint32_t *flag);
 // *flag into host_totals->error, flag zeroed, host_totals->pad stamped (as launch_rlev2_strided_values ends)
 hipError_t launch_spec_publish(hipStream_t st, uint32_t *flag, ScanTotals *host_totals, uint32_t stamp);
 // Value expansion without a header scan, for the column whose every window of 512 values is one

@@ -2004,8 +2004,9 @@ hipError_t launch_rlev2_strided_values(hipStream_t st, const uint8_t *stream, ui
 // varints, so positions are not arithmetic as they are for Direct runs.  One lane per run *guesses*:
 // it interpolates between the entry points on both sides of its segment and looks, in the 64 bytes
 // around that offset, for the two bytes every header of a 512-value run of the segment's kind and
-// width starts with.  One hit is the guess; none or several, and the lane walks the chain from
-// the segment's entry point instead (at most 64 hops, else the column is not for this path).
+// width starts with.  One hit is the guess; none or several, and the lane takes the end of the run
+// its neighbour guessed, or failing that walks the chain from the segment's entry point (at most
+// 64 hops, else the column is not for this path).
 // Guesses prove nothing; the links do.  Window g's run must hold 512 values and end exactly where
 // lane g + 1 says run g + 1 starts, the first run of a segment starts at its entry point, and so,
 // by induction over g, every position is the one a walk of the header chain arrives at
@@ -2023,17 +2024,15 @@ __device__ __forceinline__ uint64_t zero_bytes(uint64_t v) {
 
 constexpr uint32_t PLAN_MAX_WALK = 64;
 
-__global__ __launch_bounds__(256) void rlev2_regular_plan_kernel(
+// One lane's share of the plan: window g64 of the column (any lane whose window lies past the last
+// one to plan computes a copy of a neighbour and is not looked at).  `live`: this lane's window is
+// to be checked and delivered; all 64 lanes must be here (the links go through shuffles).
+// Returns the window's entry (desc 0: no entry, and *flag has been raised).
+__device__ __forceinline__ RunEntry plan_window(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries, uint32_t n_seg,
-    uint32_t n_win, uint32_t r_lo, uint32_t r_hi, uint64_t num_values, int is_signed,
-    RunEntry *__restrict__ group_run, uint32_t *__restrict__ flag) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave_id = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-    const uint64_t g64 = wave_id * 63 + lane;
-    if (wave_id * 63 >= n_win) return;  // whole wavefront
-    if (__builtin_amdgcn_readfirstlane(*(const volatile uint32_t *)flag)) return;
-    const bool live = g64 < n_win;
-    const uint32_t g = live ? (uint32_t)g64 : n_win - 1;
+    uint32_t n_win, uint32_t r_lo, uint32_t r_hi, uint64_t num_values, int is_signed, uint64_t g64,
+    uint32_t lane, bool live, uint32_t *__restrict__ flag) {
+    const uint32_t g = g64 < n_win ? (uint32_t)g64 : n_win - 1;
     bool bad = false;
     // Runs per segment: the counts of windows and entry points leave r_lo .. r_hi (one value for
     // any column of many segments); among several, the one nearest to what the stream's average
@@ -2118,8 +2117,31 @@ __global__ __launch_bounds__(256) void rlev2_regular_plan_kernel(
         w.lo = sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0;
         w.hi = sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1;
     }
+    ParsedRun r;
+    r.run_end = 0;
+    r.base = 0;
+    r.aux = 0;
+    r.kind = 0;
+    r.len = 0;
+    bool parsed = false;
+    if (found && !bad) {
+        if (pos >= len || parse_run(w, s, len, pos, is_signed, r) != SEG_OK) bad = true;
+        parsed = !bad;
+    }
+    // No guess, or several: where the lane before says its run ends, if it had one guess (the links
+    // below prove the whole of it or fail) ...
+    {
+        const uint64_t prev_end = shfl_up64(r.run_end, 1);
+        const bool prev_parsed = __shfl_up((int)parsed, 1) != 0;
+        if (!found && !bad && lane > 0 && prev_parsed && g64 < n_win) {
+            pos = prev_end;
+            if (pos >= len || parse_run(load_window(s, len, pos), s, len, pos, is_signed, r) != SEG_OK) bad = true;
+            parsed = !bad;
+            found = true;
+        }
+    }
     if (!found && !bad) {
-        // no guess: the chain from the entry point, a run at a time
+        // ... else the chain from the entry point, a run at a time
         if (k > PLAN_MAX_WALK) bad = true;
         pos = e0;
         for (uint32_t j = 0; j < k && !bad; j++) {
@@ -2129,26 +2151,18 @@ __global__ __launch_bounds__(256) void rlev2_regular_plan_kernel(
             else
                 pos = hop.run_end;
         }
-        if (!bad && pos < len) w = load_window(s, len, pos);
+        if (!bad && (pos >= len || parse_run(load_window(s, len, pos), s, len, pos, is_signed, r) != SEG_OK))
+            bad = true;
     }
-    ParsedRun r;
-    r.run_end = 0;
-    r.base = 0;
-    r.aux = 0;
-    r.kind = 0;
     uint64_t desc = 0;
     if (!bad) {
-        if (pos >= len || parse_run(w, s, len, pos, is_signed, r) != SEG_OK) {
+        desc = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes) | DESC_SINGLE;
+        const uint64_t wbase = (uint64_t)g << WINDOW_SHIFT;
+        if (g + 1 == n_win) {
+            // the column's last run: any length that holds the values still wanted
+            if (wbase >= num_values || (uint64_t)r.len < num_values - wbase) bad = true;
+        } else if (r.len != WINDOW) {
             bad = true;
-        } else {
-            desc = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes) | DESC_SINGLE;
-            const uint64_t wbase = (uint64_t)g << WINDOW_SHIFT;
-            if (g + 1 == n_win) {
-                // the column's last run: any length that holds the values still wanted
-                if (wbase >= num_values || (uint64_t)r.len < num_values - wbase) bad = true;
-            } else if (r.len != WINDOW) {
-                bad = true;
-            }
         }
     }
     // the link: this run ends where the next lane's begins (lanes past the last window mirror it
@@ -2164,26 +2178,42 @@ __global__ __launch_bounds__(256) void rlev2_regular_plan_kernel(
     if (linked && (r.kind != KIND_DIRECT || (g + 2 < n_win && size != next_size))) {
         if (__builtin_amdgcn_readfirstlane(*(const volatile uint32_t *)(flag + 1)) == 0) atomicOr(flag + 1, 1u);
     }
-    if (live && lane < 63 && !bad) {
-        RunEntry e;
-        e.desc = desc;
-        e.out_off = (uint64_t)g << WINDOW_SHIFT;
-        e.base = r.base;
-        e.aux = r.aux;
-        group_run[g] = e;
-    }
+    RunEntry e;
+    e.desc = (live && lane < 63 && !bad) ? desc : 0;
+    e.out_off = (uint64_t)g << WINDOW_SHIFT;
+    e.base = r.base;
+    e.aux = r.aux;
+    return e;
+}
+
+__global__ __launch_bounds__(256) void rlev2_regular_plan_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries, uint32_t n_seg,
+    uint32_t n_win, uint32_t r_lo, uint32_t r_hi, uint64_t num_values, int is_signed,
+    RunEntry *__restrict__ group_run, uint32_t *__restrict__ flag) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint64_t g64 = wave_id * 63 + lane;
+    if (wave_id * 63 >= n_win) return;  // whole wavefront
+    if (__builtin_amdgcn_readfirstlane(*(const volatile uint32_t *)flag)) return;
+    const RunEntry e = plan_window(s, len, entries, n_seg, n_win, r_lo, r_hi, num_values, is_signed, g64, lane,
+                                   g64 < n_win, flag);
+    if (e.desc != 0) group_run[g64] = e;
+}
+
+bool rlev2_regular_plan_shape(uint32_t n_seg, uint32_t n_win, uint32_t *r_lo, uint32_t *r_hi) {
+    if (n_win == 0 || n_seg < 2 || n_seg > n_win) return false;
+    // n_win = (n_seg - 1) * runs_per_seg + (1 .. runs_per_seg windows of the last segment)
+    *r_lo = (n_win + n_seg - 1) / n_seg;
+    *r_hi = (n_win - 1) / (n_seg - 1);
+    return *r_lo <= *r_hi;
 }
 
 hipError_t launch_rlev2_regular_plan(hipStream_t st, const uint8_t *stream, uint64_t len,
                                      const uint64_t *entries, uint32_t n_seg, uint32_t n_win,
                                      uint64_t num_values, int is_signed, RunEntry *group_run,
-                                     uint32_t *flag, bool *eligible) {
-    *eligible = false;
-    if (n_win == 0 || n_seg < 2 || n_seg > n_win || !entries) return hipSuccess;
-    // n_win = (n_seg - 1) * runs_per_seg + (1 .. runs_per_seg windows of the last segment)
-    const uint32_t r_lo = (n_win + n_seg - 1) / n_seg, r_hi = (n_win - 1) / (n_seg - 1);
-    if (r_lo > r_hi) return hipSuccess;
-    *eligible = true;
+                                     uint32_t *flag) {
+    uint32_t r_lo, r_hi;
+    if (!entries || !rlev2_regular_plan_shape(n_seg, n_win, &r_lo, &r_hi)) return hipErrorInvalidValue;
     const uint64_t waves = ((uint64_t)n_win + 62) / 63;
     rlev2_regular_plan_kernel<<<(uint32_t)((waves + 3) / 4), 256, 0, st>>>(
         stream, len, entries, n_seg, n_win, r_lo, r_hi, num_values, is_signed, group_run, flag);

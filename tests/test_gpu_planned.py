@@ -222,3 +222,26 @@ def test_unaligned_device_output(ctx, oracle):
         ctx.synchronize()
         assert (out.cpu().numpy() == vals).all()
         assert ctx.last_path() == PATH_PLANNED
+
+
+@pytest.mark.parametrize("n_runs,cut", [(400, 0), (401, 0), (417, 100), (1000, 0)])
+def test_planned_then_broken(ctx, oracle, n_runs, cut):
+    """Longer columns, decoded repeatedly on one context; then the same column with one run near
+    its end claiming 511 values: the plan fails and the general path gives the oracle's answer."""
+    rng = np.random.default_rng(n_runs + cut)
+    stream, vals, starts = delta_column(rng, n_runs, 10, True, small_steps=0.2)
+    for _ in range(3):
+        check(ctx, oracle, stream, vals.size - cut, True, every(starts, 5), PATH_PLANNED, vals)
+    broken = bytearray(stream)
+    broken[starts[n_runs - 30] + 1] = 0xFE   # that run now claims 511 values
+    out = None
+    try:
+        out = ctx.rlev2(bytes(broken), vals.size - cut, True, every(starts, 5))
+    except Exception:
+        pass
+    rc, ref, _ = oracle.rlev2(bytes(broken), vals.size - cut, True)
+    if rc == 0:
+        assert out is not None and (out == ref).all()
+    else:
+        assert out is None
+    assert ctx.last_path() == PATH_GENERAL
