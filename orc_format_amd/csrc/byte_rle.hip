@@ -481,12 +481,20 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
             // offset from src0 (runs of one tile lie within 64 * 131 stream bytes), run flag on top
             const uint32_t my_srel = (uint32_t)((my_src & PAYLOAD_MASK) - src0) |
                                      ((my_src & BR_IS_RUN) ? 0x80000000u : 0u);
-            // all addressing below is 32-bit, relative to the aligned dword at or before s + src0
+            // all addressing below is 32-bit, relative to s + src0
             const uint8_t *sb = s + src0;
             const uint32_t skew = (uint32_t)((uintptr_t)sb & 3);
-            const uint32_t *sw = (const uint32_t *)(sb - skew);
+            const uint32_t *sw = (const uint32_t *)(sb - skew);  // the aligned dword at or before s + src0
             const uint64_t avail = len > src0 ? len - src0 : 0;  // stream bytes from src0 on
-            const uint32_t lim = avail > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)avail;
+            // the last offset a load may use: every byte that is wanted lies inside a run, and the
+            // scan has checked every run against the stream's length, so only bytes past the last
+            // value (which are masked out below) can point further -- those are clamped
+            const uint32_t last = (avail > 0xFFFF0000ull ? 0xFFFF0000u : (avail ? (uint32_t)avail - 1u : 0u)) + skew;
+            // A byte at tile position q inside run k comes from offset base_k + (q & mask_k):
+            // a literal's bytes follow one another (base = source - start, mask = all ones), a
+            // run's all come from its one value byte (base = source, mask = 0).
+            const uint32_t my_mask = (my_srel >> 31) ? 0u : 0xFFFFFFFFu;
+            const uint32_t my_base = (my_srel & 0x7FFFFFFFu) + skew - ((uint32_t)my_rel & my_mask);
             uint32_t boff[BOOL_STEPS][2];
 #pragma unroll
             for (uint32_t step = 0; step < BOOL_STEPS; step++) {
@@ -496,16 +504,17 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
                 const int32_t p_first = (int32_t)(128 * step);
                 const uint32_t kf = (uint32_t)__popcll(__ballot(my_rel <= p_first)) - 1u;
                 const uint32_t kl = (uint32_t)__popcll(__ballot(my_rel <= p_first + 127)) - 1u;
-                int32_t rel_k, rel_n;
-                uint32_t srel_k, srel_n;
+                int32_t rel_n;
+                uint32_t base_k, base_n, mask_k, mask_n;
                 if (kl <= kf + 1) {
                     // at most two runs under the step (runs of a hundred bytes and more are the
                     // common case): their fields are wave-uniform, no lane has to search
                     const int a = __builtin_amdgcn_readfirstlane((int)kf), b = (a + 1) & 63;
-                    rel_k = __builtin_amdgcn_readlane(my_rel, a);
                     rel_n = a == 63 ? 0x7FFFFFFF : __builtin_amdgcn_readlane(my_rel, b);
-                    srel_k = __builtin_amdgcn_readlane(my_srel, a);
-                    srel_n = __builtin_amdgcn_readlane(my_srel, b);
+                    base_k = __builtin_amdgcn_readlane(my_base, a);
+                    base_n = __builtin_amdgcn_readlane(my_base, b);
+                    mask_k = __builtin_amdgcn_readlane(my_mask, a);
+                    mask_n = __builtin_amdgcn_readlane(my_mask, b);
                 } else {
                     // largest k with rel[k] <= p (lanes past the last run hold INT_MAX; rel[0] <= 0)
                     int k = 0;
@@ -514,22 +523,19 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
                         const int32_t v = __shfl(my_rel, k + sft);
                         if (v <= p) k += sft;
                     }
-                    rel_k = __shfl(my_rel, k);
                     rel_n = __shfl(my_rel, (k + 1) & 63);
                     if (k == 63) rel_n = 0x7FFFFFFF;  // no run after the 64th
-                    srel_k = __shfl(my_srel, k);
-                    srel_n = __shfl(my_srel, (k + 1) & 63);
+                    base_k = __shfl(my_base, k);
+                    base_n = __shfl(my_base, (k + 1) & 63);
+                    mask_k = __shfl(my_mask, k);
+                    mask_n = __shfl(my_mask, (k + 1) & 63);
                 }
-                // where this lane's two bytes lie, as byte offsets from the aligned dword at or
-                // before s + src0 (0xFFFFFFFF: past the stream, reads as zero)
 #pragma unroll
                 for (uint32_t h = 0; h < 2; h++) {
                     const int32_t q = p + (int32_t)h;
                     const bool next = q >= rel_n;  // runs are not empty: the next byte is in k or k + 1
-                    const uint32_t srel = next ? srel_n : srel_k;
-                    const int32_t rel = next ? rel_n : rel_k;
-                    const uint32_t off = (srel & 0x7FFFFFFFu) + ((srel >> 31) ? 0u : (uint32_t)(q - rel));
-                    boff[step][h] = off < lim ? off + skew : 0xFFFFFFFFu;
+                    const uint32_t off = (next ? base_n : base_k) + ((uint32_t)q & (next ? mask_n : mask_k));
+                    boff[step][h] = off < last ? off : last;
                 }
             }
             // all the tile's stream loads go out together (as aligned dwords: a byte-sized load
@@ -537,9 +543,9 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
             uint32_t word[BOOL_STEPS][2];
 #pragma unroll
             for (uint32_t step = 0; step < BOOL_STEPS; step++) {
-                word[step][0] = boff[step][0] != 0xFFFFFFFFu ? sw[boff[step][0] >> 2] : 0u;
+                word[step][0] = avail ? sw[boff[step][0] >> 2] : 0u;
                 const bool same = (boff[step][1] >> 2) == (boff[step][0] >> 2);
-                word[step][1] = (!same && boff[step][1] != 0xFFFFFFFFu) ? sw[boff[step][1] >> 2] : 0u;
+                word[step][1] = (!same && avail) ? sw[boff[step][1] >> 2] : 0u;
             }
 #pragma unroll
             for (uint32_t step = 0; step < BOOL_STEPS; step++) {
