@@ -55,6 +55,7 @@ EXTRA_WORKLOADS = ["delta_w10", "delta_w16", "mixed_short_runs", "boolean_mix", 
 # the offsets); stripes of 2 000 000 strings, about 64 MB of DATA each
 FILE_STRIPES, FILE_STRINGS_PER_STRIPE = 32, 2_000_000
 FILE_CONTEXTS = int(os.environ.get("ORCD_BENCH_FILE_CONTEXTS", "4"))
+FILE_PREFETCH = os.environ.get("ORCD_BENCH_FILE_PREFETCH", "1") != "0"   # stripes read ahead in the background
 
 
 def spawn_ranks(args):
@@ -447,7 +448,7 @@ def bench_strings_file(args, rank, world, local_rank, dist, torch, np):
         def one_pass():
             return shard.decode_file_shard(contexts[0], md, 0, 1, columns=[1], row_aligned=False,
                                            check_utf8=True, extra_contexts=contexts[1:], device=True,
-                                           on_stripe=on_stripe)
+                                           on_stripe=on_stripe, prefetch=FILE_PREFETCH)
 
         def barrier():
             torch.cuda.synchronize()
@@ -481,7 +482,8 @@ def bench_strings_file(args, rank, world, local_rank, dist, torch, np):
         "decoded_GBps": round(decoded[0] * world / elapsed / 1e9, 2),
         "config": {"workload": "strings_file: uncompressed ORC file of %d stripes x %d strings, lengths "
                                "U[8,56] as RLE v2 Direct width 6, ASCII DATA (seed 46), %d bytes per GPU; "
-                               "%d contexts per GPU" % (n_stripes, FILE_STRINGS_PER_STRIPE, size, FILE_CONTEXTS),
+                               "%d contexts per GPU%s" % (n_stripes, FILE_STRINGS_PER_STRIPE, size, FILE_CONTEXTS,
+                                                          ", each reading its next stripe ahead" if FILE_PREFETCH else ""),
                    "file_bytes_per_gpu": size, "stripes": n_stripes,
                    "parallelism": "stripe-sharded x%d" % world},
     }

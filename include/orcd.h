@@ -417,6 +417,20 @@ int orcd_decode_stripe(orcd_ctx *ctx, orcd_file *file, size_t stripe,
                        const orcd_stripe_footer *footer, const uint32_t *columns, size_t n_columns,
                        unsigned flags, orcd_column_data *out);
 
+/* A hint that orcd_decode_stripe will be called for these columns of this stripe: a background
+ * thread of the context starts the one read of the region the columns span (what
+ * read_stripe_column does with one seek and one read per column, src/read/mod.rs:117-159) and its
+ * copy to the device, with pinned chunks, reader threads and a stream of its own, so that they run
+ * beside the decode of the stripe before.  The decode call for the same file, stripe and columns
+ * then waits for those bytes instead of reading them; with other arguments it reads for itself and
+ * the bytes read ahead stay until they are claimed or the context is destroyed.  At most two
+ * stripes are kept ahead (further hints are ignored), served in the order given; compressed files
+ * are not read ahead.  `file` and `footer` must stay open until the stripe has been decoded or the
+ * context destroyed.  Returns what finding the region returns (ORCD_INVALID_COLUMN, ORCD_OUT_OF_SPEC
+ * for a region outside the file, ...); a failed read shows when the stripe is decoded. */
+int orcd_stripe_prefetch(orcd_ctx *ctx, orcd_file *file, size_t stripe,
+                         const orcd_stripe_footer *footer, const uint32_t *columns, size_t n_columns);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,7 @@ SIGNATURES = {
     "orcd_decode_column": (C.c_int, [P, P, SZ, P, C.c_uint32, C.c_uint, C.POINTER(ColumnData)]),
     "orcd_column_data_free": (None, [C.POINTER(ColumnData)]),
     "orcd_decode_stripe": (C.c_int, [P, P, SZ, P, C.POINTER(C.c_uint32), SZ, C.c_uint, C.POINTER(ColumnData)]),
+    "orcd_stripe_prefetch": (C.c_int, [P, P, SZ, P, C.POINTER(C.c_uint32), SZ]),
 }
 
 _lib = None

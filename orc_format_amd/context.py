@@ -272,6 +272,15 @@ class Context:
             for cd in cds:
                 self._lib.orcd_column_data_free(C.byref(cd))
 
+    def stripe_prefetch(self, metadata, stripe, footer, columns):
+        """orcd_stripe_prefetch: starts reading these columns of this stripe and copying them to the
+        device in the background; the decode_stripe call for the same stripe and columns then finds
+        the bytes there.  `metadata` and `footer` must be kept until that call (or the context's
+        end): the caller holds on to them."""
+        cols = (C.c_uint32 * len(columns))(*columns)
+        check(self._lib.orcd_stripe_prefetch(self._h, metadata._h, stripe, footer._h, cols, len(columns)),
+              self._h)
+
     def rlev2_batch(self, buffer, slices, signed, out_ptr=0, device=False):
         """orcd_rlev2_decode_batch.  `slices`: (offset, length, num_values, entry_points or None)
         per stream inside `buffer` (host bytes / numpy, or with device=True a raw device address

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
@@ -180,6 +181,50 @@ struct CopyThreads {
     }
 };
 
+// What one party needs to move large transfers: pinned chunks, an event per chunk, parked threads.
+// The calling thread of a context has one set; the background reader of orcd_stripe_prefetch has
+// another, with a stream of its own.
+struct StageSet {
+    uint8_t *h_stage[N_READERS] = {};  // pinned chunks, allocated on first use
+    hipEvent_t ev_stage[N_READERS] = {};
+    bool stage_busy[N_READERS] = {};   // a copy out of the chunk was queued and not yet waited for
+    CopyThreads *copy_threads = nullptr;
+    hipStream_t stream = nullptr;      // where its copies are queued (null: the context's stream)
+    void release() {
+        for (int i = 0; i < N_READERS; i++) {
+            if (h_stage[i]) (void)hipHostFree(h_stage[i]);
+            if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]);
+            h_stage[i] = nullptr;
+            ev_stage[i] = nullptr;
+        }
+        delete copy_threads;
+        copy_threads = nullptr;
+    }
+};
+
+// One stripe's bytes on their way to the device ahead of the decode call that wants them.
+struct PrefetchJob {
+    orcd_file *file = nullptr;
+    size_t stripe = 0;
+    uint64_t file_off = 0, len = 0;  // the region of the file
+    void *d_buf = nullptr;           // a block of the context's device cache
+    int status = ORCD_OK;
+    bool done = false;
+};
+
+// The background reader of a context: one thread that takes the queued regions in order and moves
+// each through its own stage set (so up to N_READERS threads read and copy side by side while
+// the context's own thread decodes the stripe before).
+struct Prefetcher {
+    static constexpr size_t MAX_JOBS = 2;
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable wake, finished;
+    std::deque<PrefetchJob *> jobs;  // queued, being read, or read and not yet claimed -- oldest first
+    bool stop = false;
+    StageSet stage;
+};
+
 // ---- device memory of orcd_rlev2_decode_noalloc ------------------------------------------------
 // That entry point may not allocate, so everything its kernels keep beside the caller's input and
 // output -- segment counts and offsets, workgroup totals, the run table, the per-window tables, the
@@ -242,10 +287,8 @@ struct orcd_ctx {
     ScanTotals *h_totals = nullptr;  // pinned, coherent: the scan kernel writes it
     uint32_t totals_stamp = 0;
     uint64_t *h_scalars = nullptr;   // pinned, 8 words
-    uint8_t *h_stage[N_READERS] = {};  // pinned chunks for large host transfers, allocated on first use
-    hipEvent_t ev_stage[N_READERS] = {};
-    bool stage_busy[N_READERS] = {};   // a copy out of the chunk was queued and not yet waited for
-    CopyThreads *copy_threads = nullptr;
+    StageSet stage;                    // large host transfers of the calling thread, queued on `stream`
+    Prefetcher *prefetcher = nullptr;  // background reader of stripes to come (orcd_stripe_prefetch)
     // Result arrays and per-call temporaries of the column calls: released blocks are kept and
     // handed out again (see dev_alloc).
     BlockCache dev_cache{false};   // device memory
@@ -262,6 +305,8 @@ struct orcd_ctx {
 };
 
 namespace {
+
+void prefetch_shutdown(orcd_ctx *c);
 
 #define HIP_TRY(ctx, expr)                     \
     do {                                       \
@@ -318,18 +363,19 @@ struct HostSource {       // where the bytes of a transfer to the device come fr
 constexpr size_t CHUNK_MIN = 1u << 20;
 
 template <typename Step>
-int run_chunked(orcd_ctx *c, uint64_t len, Step step) {
+int run_chunked(orcd_ctx *c, StageSet &ss, uint64_t len, Step step) {
+    hipStream_t st = ss.stream ? ss.stream : c->stream;
     for (int i = 0; i < N_READERS; i++) {
-        if (!c->h_stage[i]) HIP_TRY(c, hipHostMalloc((void **)&c->h_stage[i], STAGE_CHUNK, hipHostMallocDefault));
-        if (!c->ev_stage[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+        if (!ss.h_stage[i]) HIP_TRY(c, hipHostMalloc((void **)&ss.h_stage[i], STAGE_CHUNK, hipHostMallocDefault));
+        if (!ss.ev_stage[i]) HIP_TRY(c, hipEventCreateWithFlags(&ss.ev_stage[i], hipEventDisableTiming));
     }
     uint64_t chunk = (len / N_READERS + CHUNK_MIN - 1) / CHUNK_MIN * CHUNK_MIN;
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, CHUNK_MIN), STAGE_CHUNK);
     const uint64_t n_chunks = (len + chunk - 1) / chunk;
     int n_threads = (int)std::min<uint64_t>(N_READERS, n_chunks);
     if (n_threads > 1) {
-        if (!c->copy_threads) c->copy_threads = new (std::nothrow) CopyThreads();
-        n_threads = c->copy_threads ? std::min(n_threads, c->copy_threads->ensure(n_threads - 1) + 1) : 1;
+        if (!ss.copy_threads) ss.copy_threads = new (std::nothrow) CopyThreads();
+        n_threads = ss.copy_threads ? std::min(n_threads, ss.copy_threads->ensure(n_threads - 1) + 1) : 1;
     }
     std::atomic<int> status{ORCD_OK};
     std::atomic<int> hip_status{(int)hipSuccess};
@@ -352,53 +398,58 @@ int run_chunked(orcd_ctx *c, uint64_t len, Step step) {
     if (n_threads <= 1) {
         if (n_chunks) worker(0);
     } else {
-        c->copy_threads->run(n_threads, worker);
+        ss.copy_threads->run(n_threads, worker);
     }
     if (status != ORCD_OK) {
         if (hip_status != (int)hipSuccess) c->last_hip = (hipError_t)hip_status.load();
-        (void)hipStreamSynchronize(c->stream);  // queued copies still use the pinned chunks
-        for (int i = 0; i < N_READERS; i++) c->stage_busy[i] = false;
+        (void)hipStreamSynchronize(st);  // queued copies still use the pinned chunks
+        for (int i = 0; i < N_READERS; i++) ss.stage_busy[i] = false;
         return status;
     }
     return ORCD_OK;
 }
 
-// src -> d_dst, queued on the context's stream (the copies may still be running on return)
-int chunked_to_device(orcd_ctx *c, const HostSource &src, uint64_t len, uint8_t *d_dst) {
-    return run_chunked(c, len, [&](int t, uint64_t pos, uint64_t n, hipError_t *e) -> int {
-        if (c->stage_busy[t]) {  // the chunk's last copy is done
-            *e = hipEventSynchronize(c->ev_stage[t]);
+// src -> d_dst, queued on the set's stream (the copies may still be running on return)
+int chunked_to_device(orcd_ctx *c, StageSet &ss, const HostSource &src, uint64_t len, uint8_t *d_dst) {
+    hipStream_t st = ss.stream ? ss.stream : c->stream;
+    return run_chunked(c, ss, len, [&](int t, uint64_t pos, uint64_t n, hipError_t *e) -> int {
+        if (ss.stage_busy[t]) {  // the chunk's last copy is done
+            *e = hipEventSynchronize(ss.ev_stage[t]);
             if (*e != hipSuccess) return ORCD_HIP_ERROR;
-            c->stage_busy[t] = false;
+            ss.stage_busy[t] = false;
         }
         if (src.file) {
-            const int rc = orcd_file_read_at(src.file, src.file_off + pos, n, c->h_stage[t]);
+            const int rc = orcd_file_read_at(src.file, src.file_off + pos, n, ss.h_stage[t]);
             if (rc != ORCD_OK) return rc;
         } else {
-            memcpy(c->h_stage[t], src.mem + pos, n);
+            memcpy(ss.h_stage[t], src.mem + pos, n);
         }
-        *e = hipMemcpyAsync(d_dst + pos, c->h_stage[t], n, hipMemcpyHostToDevice, c->stream);
-        if (*e == hipSuccess) *e = hipEventRecord(c->ev_stage[t], c->stream);
+        *e = hipMemcpyAsync(d_dst + pos, ss.h_stage[t], n, hipMemcpyHostToDevice, st);
+        if (*e == hipSuccess) *e = hipEventRecord(ss.ev_stage[t], st);
         if (*e != hipSuccess) return ORCD_HIP_ERROR;
-        c->stage_busy[t] = true;
+        ss.stage_busy[t] = true;
         return ORCD_OK;
     });
+}
+int chunked_to_device(orcd_ctx *c, const HostSource &src, uint64_t len, uint8_t *d_dst) {
+    return chunked_to_device(c, c->stage, src, len, d_dst);
 }
 
 // d_src -> h_dst; everything queued on the stream before has finished and the bytes are in
 // h_dst on return
 int chunked_to_host(orcd_ctx *c, const uint8_t *d_src, uint64_t len, uint8_t *h_dst) {
-    return run_chunked(c, len, [&](int t, uint64_t pos, uint64_t n, hipError_t *e) -> int {
-        if (c->stage_busy[t]) {
-            *e = hipEventSynchronize(c->ev_stage[t]);
+    StageSet &ss = c->stage;
+    return run_chunked(c, ss, len, [&](int t, uint64_t pos, uint64_t n, hipError_t *e) -> int {
+        if (ss.stage_busy[t]) {
+            *e = hipEventSynchronize(ss.ev_stage[t]);
             if (*e != hipSuccess) return ORCD_HIP_ERROR;
-            c->stage_busy[t] = false;
+            ss.stage_busy[t] = false;
         }
-        *e = hipMemcpyAsync(c->h_stage[t], d_src + pos, n, hipMemcpyDeviceToHost, c->stream);
-        if (*e == hipSuccess) *e = hipEventRecord(c->ev_stage[t], c->stream);
-        if (*e == hipSuccess) *e = hipEventSynchronize(c->ev_stage[t]);
+        *e = hipMemcpyAsync(ss.h_stage[t], d_src + pos, n, hipMemcpyDeviceToHost, c->stream);
+        if (*e == hipSuccess) *e = hipEventRecord(ss.ev_stage[t], c->stream);
+        if (*e == hipSuccess) *e = hipEventSynchronize(ss.ev_stage[t]);
         if (*e != hipSuccess) return ORCD_HIP_ERROR;
-        memcpy(h_dst + pos, c->h_stage[t], n);
+        memcpy(h_dst + pos, ss.h_stage[t], n);
         return ORCD_OK;
     });
 }
@@ -978,13 +1029,10 @@ int orcd_ctx_destroy(orcd_ctx *c) try {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
-    for (int i = 0; i < N_READERS; i++) {
-        if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
-        if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
-    }
+    prefetch_shutdown(c);  // (joins the background reader; its device blocks go back to the cache)
+    c->stage.release();
     c->dev_cache.release_all();
     c->host_cache.release_all();
-    delete c->copy_threads;
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return ORCD_OK;
@@ -1849,6 +1897,134 @@ void dev_free(orcd_ctx *c, void *p) {
     if (!c->dev_cache.give_back(p, c->dev_cache_limit)) (void)hipFree(p);  // not one of ours
 }
 
+// ---- stripes read ahead ------------------------------------------------------------------------
+// Reading a stripe's bytes and copying them to the device takes longer than decoding them, and a
+// context does one thing at a time.  orcd_stripe_prefetch hands the read of a stripe to come to a
+// background thread of the context, with pinned chunks, reader threads and a stream of its own;
+// orcd_decode_stripe, when it finds the region it needs among the jobs, waits for that job instead
+// of reading.  Jobs are served oldest first, at most Prefetcher::MAX_JOBS are kept.
+
+void prefetch_serve(orcd_ctx *c) {
+    Prefetcher *pf = c->prefetcher;
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        PrefetchJob *job = nullptr;
+        {
+            std::unique_lock<std::mutex> lock(pf->m);
+            pf->wake.wait(lock, [&] {
+                if (pf->stop) return true;
+                for (PrefetchJob *j : pf->jobs)
+                    if (!j->done) return true;
+                return false;
+            });
+            if (pf->stop) return;
+            for (PrefetchJob *j : pf->jobs)
+                if (!j->done) {
+                    job = j;
+                    break;
+                }
+        }
+        const HostSource region = {job->file, job->file_off, nullptr};
+        int rc = chunked_to_device(c, pf->stage, region, job->len, (uint8_t *)job->d_buf);
+        // the bytes are on the device when the job is reported done: whoever claims it needs no
+        // ordering against this thread's stream
+        if (hipStreamSynchronize(pf->stage.stream) != hipSuccess && rc == ORCD_OK) rc = ORCD_HIP_ERROR;
+        for (int i = 0; i < N_READERS; i++) pf->stage.stage_busy[i] = false;
+        {
+            std::lock_guard<std::mutex> lock(pf->m);
+            job->status = rc;
+            job->done = true;
+        }
+        pf->finished.notify_all();
+    }
+}
+
+int prefetch_start(orcd_ctx *c) {
+    if (c->prefetcher) return ORCD_OK;
+    Prefetcher *pf = new Prefetcher();
+    if (hipStreamCreateWithFlags(&pf->stage.stream, hipStreamNonBlocking) != hipSuccess) {
+        delete pf;
+        return ORCD_HIP_ERROR;
+    }
+    c->prefetcher = pf;
+    pf->worker = std::thread([c] { prefetch_serve(c); });
+    return ORCD_OK;
+}
+
+void prefetch_shutdown(orcd_ctx *c) {
+    Prefetcher *pf = c->prefetcher;
+    if (!pf) return;
+    {
+        std::lock_guard<std::mutex> lock(pf->m);
+        pf->stop = true;
+    }
+    pf->wake.notify_all();
+    if (pf->worker.joinable()) pf->worker.join();  // (a read that is under way finishes first)
+    for (PrefetchJob *j : pf->jobs) {
+        dev_free(c, j->d_buf);
+        delete j;
+    }
+    pf->jobs.clear();
+    if (pf->stage.stream) {
+        (void)hipStreamSynchronize(pf->stage.stream);
+        pf->stage.release();
+        (void)hipStreamDestroy(pf->stage.stream);
+    }
+    delete pf;
+    c->prefetcher = nullptr;
+}
+
+// The device copy of file[file_off, file_off + len) of `stripe`, if it was asked for ahead of
+// time: waits for the read, hands the block over (the caller owns it then) or returns null (never
+// asked for, or the read failed: the caller reads for itself and reports what it finds).
+void *prefetch_claim(orcd_ctx *c, orcd_file *file, size_t stripe, uint64_t file_off, uint64_t len) {
+    Prefetcher *pf = c->prefetcher;
+    if (!pf) return nullptr;
+    std::unique_lock<std::mutex> lock(pf->m);
+    for (auto it = pf->jobs.begin(); it != pf->jobs.end(); ++it) {
+        PrefetchJob *j = *it;
+        if (j->file != file || j->stripe != stripe || j->file_off != file_off || j->len != len) continue;
+        pf->finished.wait(lock, [&] { return j->done; });
+        pf->jobs.erase(it);
+        void *buf = j->d_buf;
+        const int rc = j->status;
+        delete j;
+        if (rc != ORCD_OK) {
+            lock.unlock();
+            dev_free(c, buf);
+            return nullptr;
+        }
+        return buf;
+    }
+    return nullptr;
+}
+
+// The byte range of the stripe's data area that the columns' streams span (file offsets), the way
+// decode_stripe_impl reads it.  *len = 0: nothing to read.
+int stripe_columns_region(orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
+                          const uint32_t *columns, size_t n_columns, uint64_t *file_off, uint64_t *len) {
+    orcd_stripe_info si;
+    ORCD_TRY(orcd_file_stripe(file, stripe, &si));
+    uint64_t lo = ~0ull, hi = 0;
+    for (size_t i = 0; i < n_columns; i++) {
+        if (columns[i] >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
+        orcd_column *col = nullptr;
+        ORCD_TRY(orcd_stripe_column_open(file, stripe, footer, columns[i], &col));
+        uint64_t off = 0, n = 0;
+        const int rc = orcd_column_region(col, &off, &n);
+        orcd_column_free(col);
+        ORCD_TRY(rc);
+        if (off + n < off) return ORCD_OUT_OF_SPEC;
+        lo = std::min(lo, off);
+        hi = std::max(hi, off + n);
+    }
+    if (lo > hi) lo = hi = 0;
+    if (si.offset + lo < si.offset) return ORCD_OUT_OF_SPEC;
+    *file_off = si.offset + lo;
+    *len = hi - lo;
+    return ORCD_OK;
+}
+
 // Host results of the column calls live in pinned memory from a cache of the same kind: a copy
 // from the device into it runs at the speed of the link (into freshly malloc'd pageable memory it
 // ran at 6-14 GB/s, page faults and the runtime's staging included), and pinning is paid once.
@@ -2187,10 +2363,14 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
             uint8_t probe;
             if (sb.hi > sb.lo) ORCD_TRY(orcd_file_read_at(file, si.offset + sb.lo + (sb.hi - sb.lo - 1), 1, &probe));
         }
-        ORCD_TRY(dev_alloc(c, sb.hi - sb.lo, &stripe_mem.tmp));
+        // read ahead of time (orcd_stripe_prefetch)?  Then the bytes are on the device already.
+        stripe_mem.tmp = prefetch_claim(c, file, stripe, si.offset + sb.lo, sb.hi - sb.lo);
+        if (!stripe_mem.tmp) {
+            ORCD_TRY(dev_alloc(c, sb.hi - sb.lo, &stripe_mem.tmp));
+            const HostSource region = {file, si.offset + sb.lo, nullptr};
+            ORCD_TRY(chunked_to_device(c, region, sb.hi - sb.lo, (uint8_t *)stripe_mem.tmp));
+        }
         sb.d_base = (const uint8_t *)stripe_mem.tmp;
-        const HostSource region = {file, si.offset + sb.lo, nullptr};
-        ORCD_TRY(chunked_to_device(c, region, sb.hi - sb.lo, (uint8_t *)stripe_mem.tmp));
     }
 
     // 2. validity: the small PRESENT streams in one set of launches
@@ -2316,6 +2496,40 @@ int orcd_decode_column(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     // chunks) of the column's region and the same decode from its device copy
     return orcd_decode_stripe(c, file, stripe, footer, &column, 1, flags, out);
 }
+
+int orcd_stripe_prefetch(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
+                         const uint32_t *columns, size_t n_columns) try {
+    if (!c || !file || !footer || (n_columns && !columns)) return ORCD_INVALID_ARGUMENT;
+    if (orcd_file_compression(file) != 0) return ORCD_OK;  // (a compressed stripe is inflated by the decode call)
+    uint64_t file_off = 0, len = 0;
+    ORCD_TRY(stripe_columns_region(file, stripe, footer, columns, n_columns, &file_off, &len));
+    if (len == 0) return ORCD_OK;
+    {   // the region must lie inside the file before memory of its size is asked for
+        uint8_t probe;
+        ORCD_TRY(orcd_file_read_at(file, file_off + (len - 1), 1, &probe));
+    }
+    DeviceGuard g(c->device);
+    ORCD_TRY(prefetch_start(c));
+    Prefetcher *pf = c->prefetcher;
+    {
+        std::lock_guard<std::mutex> lock(pf->m);
+        if (pf->jobs.size() >= Prefetcher::MAX_JOBS) return ORCD_OK;  // a hint: this one is not taken
+        for (PrefetchJob *j : pf->jobs)
+            if (j->file == file && j->stripe == stripe && j->file_off == file_off && j->len == len) return ORCD_OK;
+    }
+    std::unique_ptr<PrefetchJob> job(new PrefetchJob());
+    job->file = file;
+    job->stripe = stripe;
+    job->file_off = file_off;
+    job->len = len;
+    ORCD_TRY(dev_alloc(c, len, &job->d_buf));
+    {
+        std::lock_guard<std::mutex> lock(pf->m);
+        pf->jobs.push_back(job.release());
+    }
+    pf->wake.notify_all();
+    return ORCD_OK;
+} ORCD_CATCH
 
 void orcd_column_data_free(orcd_column_data *d) {
     if (!d) return;

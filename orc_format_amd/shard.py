@@ -58,7 +58,7 @@ def sum_over_ranks(value, dist=None, device=None):
 
 
 def decode_file_shard(ctx, metadata, rank, world_size, columns=None, row_aligned=True,
-                      check_utf8=True, extra_contexts=(), device=False, on_stripe=None):
+                      check_utf8=True, extra_contexts=(), device=False, on_stripe=None, prefetch=True):
     """The stripes of an open file that fall to `rank`, decoded on that rank's context (one
     orcd_decode_stripe call per stripe).  Returns a list of (stripe index, first row of the stripe
     in the file, [column dicts as Context.decode_stripe returns them]); the ranks' lists together
@@ -72,6 +72,10 @@ def decode_file_shard(ctx, metadata, rank, world_size, columns=None, row_aligned
     len(contexts)-th of the rank's -- one after the other; one stripe's read and copy then overlap
     another's decode on a different context.
 
+    prefetch: every context has its next stripe read and copied to the device in the background
+    (orcd_stripe_prefetch) while it decodes the current one, so that even a single context overlaps
+    the feed with the decode.
+
     device: the columns stay on the GPU (context.DeviceColumn objects instead of dicts).
     on_stripe(context, stripe, columns): called by the decoding thread after each stripe, e.g. to
     copy the offsets of a string column to the host, or to free the columns when only the rate is
@@ -83,27 +87,50 @@ def decode_file_shard(ctx, metadata, rank, world_size, columns=None, row_aligned
     mine = stripes_of_rank(metadata, rank, world_size)
     contexts = [ctx] + list(extra_contexts)
 
-    def one(context, stripe):
-        footer = read.read_stripe_footer(metadata, stripe)
+    footers = {}
+
+    def footer_of(stripe):
+        if stripe not in footers:
+            footers[stripe] = read.read_stripe_footer(metadata, stripe)
+        return footers[stripe]
+
+    def ahead(context, stripe):
+        if prefetch:
+            context.stripe_prefetch(metadata, stripe, footer_of(stripe), columns)
+
+    def one(context, stripe, following=None):
+        footer = footer_of(stripe)
+        if following is not None:
+            ahead(context, following)   # read beside this stripe's decode
         cols = context.decode_stripe(metadata, stripe, footer, columns, check_utf8=check_utf8,
                                      row_aligned=row_aligned, device=device)
         if on_stripe is not None:
             cols = on_stripe(context, stripe, cols)
         return (stripe, first_rows[stripe], cols)
-    if len(contexts) == 1:
-        return [one(ctx, stripe) for stripe in mine]
-    import threading
+
+    def share(k):   # what contexts[k] decodes, in order
+        return list(range(k, len(mine), len(contexts)))
     results = [None] * len(mine)
     errors = []
 
     def drain(k):   # the only thread that ever enters contexts[k]
         try:
-            for i in range(k, len(mine), len(contexts)):
+            idx = share(k)
+            if idx:
+                ahead(contexts[k], mine[idx[0]])
+            for n, i in enumerate(idx):
                 if errors:
                     return
-                results[i] = one(contexts[k], mine[i])
+                following = mine[idx[n + 1]] if n + 1 < len(idx) else None
+                results[i] = one(contexts[k], mine[i], following)
         except BaseException as e:  # handed to the caller's thread below
             errors.append(e)
+    if len(contexts) == 1:
+        drain(0)
+        if errors:
+            raise errors[0]
+        return results
+    import threading
     threads = [threading.Thread(target=drain, args=(k,)) for k in range(len(contexts))]
     for t in threads:
         t.start()

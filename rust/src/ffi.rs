@@ -225,6 +225,9 @@ extern "C" {
     pub fn orcd_decode_stripe(ctx: *mut orcd_ctx, file: *mut orcd_file, stripe: usize,
                               footer: *const orcd_stripe_footer, columns: *const u32,
                               n_columns: usize, flags: c_uint, out: *mut orcd_column_data) -> c_int;
+    pub fn orcd_stripe_prefetch(ctx: *mut orcd_ctx, file: *mut orcd_file, stripe: usize,
+                                footer: *const orcd_stripe_footer, columns: *const u32,
+                                n_columns: usize) -> c_int;
     pub fn orcd_column_data_free(data: *mut orcd_column_data);
 }
 

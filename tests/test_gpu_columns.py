@@ -314,6 +314,13 @@ class _GuardedContext:
         finally:
             self.lock.release()
 
+    def stripe_prefetch(self, *args, **kwargs):
+        assert self.lock.acquire(blocking=False), "context entered by two threads at once"
+        try:
+            return self.ctx.stripe_prefetch(*args, **kwargs)
+        finally:
+            self.lock.release()
+
 
 def test_many_stripes_on_two_contexts_never_share_a_context(tmp_path):
     """At least four stripes per context, dealt to two contexts on two host threads (stripes are
@@ -354,6 +361,75 @@ def test_many_stripes_on_two_contexts_never_share_a_context(tmp_path):
     assert (a[a_valid] == np.array(want.column("a").drop_null().to_pylist())).all()
     assert (b == np.array(want.column("b").to_pylist())).all()
     assert (cc == np.array(want.column("c").to_pylist())).all()
+
+
+def test_stripes_read_ahead(tmp_path):
+    """orcd_stripe_prefetch: stripes read and copied to the device in the background give the
+    columns a plain decode gives -- in order, out of order, with hints that are never used, with
+    more hints than are kept, and with a context that ends while bytes are still waiting (one seek
+    and one read per column region either way: src/read/mod.rs:117-159)."""
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    from orc_format_amd import Context, read, shard
+    rng = np.random.default_rng(16)
+    rows = 600_000
+    table = pa.table({
+        "a": pa.array(rng.integers(-2**50, 2**50, size=rows), mask=rng.random(rows) < 0.1),
+        "b": pa.array(np.cumsum(rng.integers(1, 90, size=rows))),
+        "s": pa.array(["w%d" % k for k in rng.integers(0, 5000, size=rows)]),
+    })
+    path = str(tmp_path / "ahead.orc")
+    orc.write_table(table, path, compression="uncompressed", stripe_size=1 << 20)
+    md = read.read_metadata(path)
+    n = len(md.stripes)
+    assert n >= 5
+    footers = [read.read_stripe_footer(md, k) for k in range(n)]
+    cols = [1, 2, 3]
+
+    def same(x, y):
+        for cx, cy in zip(x, y):
+            assert (cx["validity"] == cy["validity"]).all()
+            for key in ("values", "offsets", "bytes"):
+                if key in cx or key in cy:
+                    assert np.array_equal(cx[key], cy[key])
+
+    with Context(0) as plain:
+        want = [plain.decode_stripe(md, k, footers[k], cols) for k in range(n)]
+    with Context(0) as ctx:
+        # in order, one and two stripes ahead
+        ctx.stripe_prefetch(md, 0, footers[0], cols)
+        for k in range(n):
+            if k + 1 < n:
+                ctx.stripe_prefetch(md, k + 1, footers[k + 1], cols)
+            same(ctx.decode_stripe(md, k, footers[k], cols), want[k])
+        # out of order: the stripe asked for is not the one decoded next; a third hint is ignored
+        ctx.stripe_prefetch(md, 3, footers[3], cols)
+        ctx.stripe_prefetch(md, 4, footers[4], cols)
+        ctx.stripe_prefetch(md, 2, footers[2], cols)
+        same(ctx.decode_stripe(md, 1, footers[1], cols), want[1])
+        same(ctx.decode_stripe(md, 4, footers[4], cols), want[4])
+        same(ctx.decode_stripe(md, 2, footers[2], cols), want[2])
+        same(ctx.decode_stripe(md, 3, footers[3], cols), want[3])
+        # other columns than were asked for: the decode reads for itself
+        ctx.stripe_prefetch(md, 0, footers[0], [2])
+        same(ctx.decode_stripe(md, 0, footers[0], cols), want[0])
+        same(ctx.decode_stripe(md, 0, footers[0], [2]), want[0][1:2])
+        # the same hint twice is one job
+        ctx.stripe_prefetch(md, 1, footers[1], cols)
+        ctx.stripe_prefetch(md, 1, footers[1], cols)
+        ctx.stripe_prefetch(md, 2, footers[2], cols)
+        same(ctx.decode_stripe(md, 2, footers[2], cols), want[2])
+        # a column that is not in the file
+        from orc_format_amd.error import OrcError
+        with pytest.raises(OrcError):
+            ctx.stripe_prefetch(md, 0, footers[0], [99])
+        # (stripe 1 is still waiting: the context ends with it)
+    # decode_file_shard reads ahead by default, on one context as on several
+    with Context(0) as one:
+        pieces = shard.decode_file_shard(one, md, 0, 1, columns=cols, row_aligned=False)
+        assert [p[0] for p in pieces] == list(range(n))
+        for k, (_, _, got) in enumerate(pieces):
+            same(got, want[k])
 
 
 def test_dictionary_column_of_a_written_file(tmp_path):

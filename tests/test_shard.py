@@ -98,7 +98,15 @@ class _ExclusiveContext:
         self.lock = threading.Lock()
         self.delays = delays
         self.seen = []
+        self.ahead = []
         self.threads = set()
+
+    def stripe_prefetch(self, metadata, stripe, footer, columns):
+        import threading
+        assert self.lock.acquire(blocking=False), "context entered by two threads at once"
+        self.threads.add(threading.get_ident())
+        self.ahead.append(stripe)
+        self.lock.release()
 
     def decode_stripe(self, metadata, stripe, footer, columns, check_utf8=True, row_aligned=False, device=False):
         import threading
@@ -133,6 +141,12 @@ def test_decode_file_shard_keeps_a_context_on_one_thread(golden_dir):
             assert all(o[2][0]["stripe"] == o[0] for o in out)
         for k, c in enumerate(ctxs):
             assert sorted(set(c.seen)) == list(range(k, n, n_ctx))
+            # every stripe was asked for ahead of its decode, by the thread that decodes it
+            assert c.ahead == c.seen
+    # without read-ahead no hint is given
+    quiet = _ExclusiveContext(delays)
+    shard.decode_file_shard(quiet, md, 0, 1, columns=[1], prefetch=False)
+    assert quiet.ahead == [] and quiet.seen == list(range(n))
 
     class Failing(_ExclusiveContext):
         def decode_stripe(self, *a, **kw):
