@@ -803,6 +803,7 @@ struct Wave {
     uint64_t len;          // its length: no load of the kernel may start at or after s + len
     uint32_t *lds;         // this wavefront's staging slice
     uint32_t *marks;       // 16 words of LDS of its own: one bit per value of a window
+    uint32_t *patch_tab;   // PATCH_TAB_WORDS words of LDS of its own, or null (see stage_patches)
     int64_t *out;
     uint64_t num_values;
     int lane;
@@ -960,8 +961,41 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v, int lane) {
     return v;
 }
 
-// PatchedBase: overwrites the patched positions of one run (all fields wave-uniform) after its
-// unpatched values have been written.  Lane j takes patch-list entry j.
+// PatchedBase: the patch list of one run (all fields wave-uniform), lane j taking entry j.
+// Returns whether this lane's entry patches a value of the run, and which (posn) with what.
+template <class W>
+__device__ __forceinline__ bool read_patch_list(const W &wv, uint64_t desc, uint64_t aux, uint32_t &posn,
+                                                uint64_t &patch) {
+    const uint32_t w = desc_width(desc), rlen = desc_len(desc);
+    const uint32_t pw = pb_patch_width(aux), pll = pb_list_len(aux), cfb = pb_entry_bits(aux);
+    const uint8_t *p = wv.s + desc_payload(desc);
+    const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
+    const uint32_t *words = (const uint32_t *)(p - sk);
+    const uint64_t list_bit = (uint64_t)sk * 8 + (((uint64_t)w * rlen + 7) >> 3) * 8;
+    posn = 0;
+    patch = 0;
+    // never read past the stream, whatever the table says (the header scan has checked this)
+    if (desc_payload(desc) + (((uint64_t)w * rlen + 7) >> 3) + (((uint64_t)cfb * pll + 7) >> 3) > wv.len)
+        return false;
+    uint64_t gap = 0;
+    if ((uint32_t)wv.lane < pll) {
+        const uint64_t entry = global_bits(words, list_bit + (uint64_t)wv.lane * cfb, cfb);
+        gap = pw >= 64 ? 0 : entry >> pw;
+        patch = pw >= 64 ? entry : entry & ((1ull << pw) - 1);
+    }
+    posn = wave_scan_u32((uint32_t)gap, wv.lane);  // position = sum of the gaps
+    const bool filler = gap == 255 && patch == 0;   // only extends the gap
+    // A zero gap after the first entry points back at a position the sequential readers have
+    // already passed: they apply neither that entry nor any later one.
+    const bool prev_filler = __shfl_up((uint32_t)filler, 1) != 0;  // a filler moves the position on
+    const uint64_t stuck =
+        __ballot((uint32_t)wv.lane < pll && wv.lane >= 1 && gap == 0 && !prev_filler);
+    const bool reachable = (stuck & ((2ull << wv.lane) - 1)) == 0;
+    return (uint32_t)wv.lane < pll && !filler && reachable && posn < rlen;
+}
+
+// PatchedBase: overwrites the patched positions of one run after its unpatched values have been
+// written.
 template <class W>
 __device__ __forceinline__ void apply_patches(const W &wv, uint64_t desc, uint64_t base,
                                               uint64_t aux, uint64_t run_out) {
@@ -969,35 +1003,40 @@ __device__ __forceinline__ void apply_patches(const W &wv, uint64_t desc, uint64
         wv.saw_patched = 1;
         return;
     }
-    const uint32_t w = desc_width(desc), rlen = desc_len(desc);
-    const uint32_t pw = pb_patch_width(aux), pll = pb_list_len(aux), cfb = pb_entry_bits(aux);
-    const uint8_t *p = wv.s + desc_payload(desc);
-    const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
-    const uint32_t *words = (const uint32_t *)(p - sk);
-    const uint64_t list_bit = (uint64_t)sk * 8 + (((uint64_t)w * rlen + 7) >> 3) * 8;
-    // never read past the stream, whatever the table says (the header scan has checked this)
-    if (desc_payload(desc) + (((uint64_t)w * rlen + 7) >> 3) + (((uint64_t)cfb * pll + 7) >> 3) > wv.len)
-        return;
-    uint64_t gap = 0, patch = 0;
-    if ((uint32_t)wv.lane < pll) {
-        const uint64_t entry = global_bits(words, list_bit + (uint64_t)wv.lane * cfb, cfb);
-        gap = pw >= 64 ? 0 : entry >> pw;
-        patch = pw >= 64 ? entry : entry & ((1ull << pw) - 1);
-    }
-    const uint32_t posn = wave_scan_u32((uint32_t)gap, wv.lane);  // position = sum of the gaps
-    const bool filler = gap == 255 && patch == 0;                 // only extends the gap
-    // A zero gap after the first entry points back at a position the sequential readers have
-    // already passed: they apply neither that entry nor any later one.
-    const bool prev_filler = __shfl_up((uint32_t)filler, 1) != 0;  // a filler moves the position on
-    const uint64_t stuck =
-        __ballot((uint32_t)wv.lane < pll && wv.lane >= 1 && gap == 0 && !prev_filler);
-    const bool reachable = (stuck & ((2ull << wv.lane) - 1)) == 0;
-    if ((uint32_t)wv.lane < pll && !filler && reachable && posn < rlen &&
-        run_out + posn < wv.num_values) {
-        uint64_t m = global_bits(words, (uint64_t)sk * 8 + (uint64_t)posn * w, w);
+    uint32_t posn;
+    uint64_t patch;
+    if (read_patch_list(wv, desc, aux, posn, patch) && run_out + posn < wv.num_values) {
+        const uint32_t w = desc_width(desc);
+        const uint8_t *p = wv.s + desc_payload(desc);
+        const uint32_t sk = (uint32_t)((uintptr_t)p & 3);
+        uint64_t m = global_bits((const uint32_t *)(p - sk), (uint64_t)sk * 8 + (uint64_t)posn * w, w);
         if (w < 64) m |= patch << w;
         stream_store1(wv.out + run_out + posn, base + m);
     }
+}
+
+// PatchedBase, ahead of the expansion: the patches of a run that has its windows to itself go into
+// the wavefront's LDS table -- byte p: 1 + the list entry that patches the run's value p, or 0;
+// behind the 512 bytes the entries' patches, 8 bytes each -- and the expansion ORs them into the
+// values before they are written, once (written afterwards, a patched value costs a wait for every
+// store of the run, two dependent reads and a partial rewrite of a line just written).
+constexpr uint32_t PATCH_TAB_WORDS = WINDOW / 4 + 2 * 32;
+
+template <class W>
+__device__ __forceinline__ void stage_patches(const W &wv, uint64_t desc, uint64_t aux) {
+    uint32_t posn;
+    uint64_t patch;
+    const bool mine = read_patch_list(wv, desc, aux, posn, patch);
+    wv.patch_tab[wv.lane] = 0;
+    wv.patch_tab[64 + wv.lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (mine) {
+        ((uint8_t *)wv.patch_tab)[posn] = (uint8_t)(wv.lane + 1);
+        ((uint64_t *)(wv.patch_tab + WINDOW / 4))[wv.lane] = patch;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // ---- a group that is one run: every run field is wave-uniform -----------------------------------
@@ -1028,13 +1067,31 @@ __device__ __forceinline__ void store_window_pair(const W &wv, int64_t *wout, ui
 
 // Direct and (unpatched) PatchedBase values of one window.  bit_lane: LDS bit position of the
 // packed field of this lane's first value of step 0.
-template <bool FULL, bool WIDE, class W>
+// PATCHED: the run is a PatchedBase run whose patches are staged (stage_patches); the lane's
+// first value of step 0 is value idx0 of the run (an even number; negative before the run).
+template <bool FULL, bool WIDE, bool PATCHED = false, class W>
 __device__ __forceinline__ void direct_window(const W &wv, int64_t *wout, uint32_t w, bool zz,
                                               uint64_t add, uint32_t bit_lane, uint32_t lo_rel,
-                                              uint32_t hi_rel) {
+                                              uint32_t hi_rel, int32_t idx0 = 0) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t i_rel = 128u * j + 2u * wv.lane;
+        uint64_t or0 = 0, or1 = 0;
+        if (PATCHED) {
+            const int32_t at = idx0 + 128 * j;  // the table covers the run's values 0..511
+            const uint32_t who = (at >= 0 && at < (int32_t)WINDOW) ? ((const uint16_t *)wv.patch_tab)[at >> 1] : 0u;
+            if (who) {
+                const uint64_t *pv = (const uint64_t *)(wv.patch_tab + WINDOW / 4);
+                if (who & 0xFFu) or0 = pv[(who & 0xFFu) - 1];
+                if (who >> 8) or1 = pv[(who >> 8) - 1];
+                if (w < 64) {
+                    or0 <<= w;
+                    or1 <<= w;
+                } else {
+                    or0 = or1 = 0;
+                }
+            }
+        }
         uint32_t bA = bit_lane + (128u * j) * w, bB = bA + w;
         if (!FULL) {  // keep the LDS reads of inactive lanes inside the slice
             if (!(i_rel >= lo_rel && i_rel < hi_rel)) bA = 0;
@@ -1047,13 +1104,13 @@ __device__ __forceinline__ void direct_window(const W &wv, int64_t *wout, uint32
                 v0 = (uint64_t)(int64_t)(int32_t)((m0 >> 1) ^ (0u - (m0 & 1u)));
                 v1 = (uint64_t)(int64_t)(int32_t)((m1 >> 1) ^ (0u - (m1 & 1u)));
             } else {
-                v0 = add + m0;
-                v1 = add + m1;
+                v0 = add + (m0 | or0);
+                v1 = add + (m1 | or1);
             }
         } else {
             const uint64_t m0 = lds_bits64(wv.lds, bA, w), m1 = lds_bits64(wv.lds, bB, w);
-            v0 = zz ? zigzag(m0) : add + m0;
-            v1 = zz ? zigzag(m1) : add + m1;
+            v0 = zz ? zigzag(m0) : add + (m0 | or0);
+            v1 = zz ? zigzag(m1) : add + (m1 | or1);
         }
         store_window_pair<FULL>(wv, wout, i_rel, v0, v1, lo_rel, hi_rel);
     }
@@ -1149,6 +1206,10 @@ __device__ __forceinline__ void decode_single_run(const W &wv, uint64_t desc, ui
     if (run_end > wv.num_values) run_end = wv.num_values;
     if (run_out >= run_end) return;  // the run starts at or after the last wanted value
     const bool packed_kind = w != 0 && kind != KIND_SHORT_REPEAT;
+    // a PatchedBase run whose first value is at an even place of its window: patches go in ahead
+    const bool patch_ahead = kind == KIND_PATCHED_BASE && W::MODE == MODE_VALUES && wv.patch_tab != nullptr &&
+                             ((run_out & 1) == 0);
+    if (patch_ahead) stage_patches(wv, desc, aux);
     uint64_t carry = 0;  // Delta: sum of the run's packed deltas before the current step
     for (uint64_t wbase = (run_out >> WINDOW_SHIFT) << WINDOW_SHIFT; wbase < run_end; wbase += WINDOW) {
         // active values of this window, relative to its start
@@ -1173,7 +1234,15 @@ __device__ __forceinline__ void decode_single_run(const W &wv, uint64_t desc, ui
             const uint64_t add = kind == KIND_PATCHED_BASE ? base : 0;
             const bool zz = kind == KIND_DIRECT && wv.is_signed;
             const uint32_t bit_lane = bit0 + (uint32_t)idx0 * w;
-            if (w <= 32) {
+            if (patch_ahead) {
+                if (w <= 32) {
+                    if (full) direct_window<true, false, true>(wv, wout, w, zz, add, bit_lane, lo_rel, hi_rel, idx0);
+                    else direct_window<false, false, true>(wv, wout, w, zz, add, bit_lane, lo_rel, hi_rel, idx0);
+                } else {
+                    if (full) direct_window<true, true, true>(wv, wout, w, zz, add, bit_lane, lo_rel, hi_rel, idx0);
+                    else direct_window<false, true, true>(wv, wout, w, zz, add, bit_lane, lo_rel, hi_rel, idx0);
+                }
+            } else if (w <= 32) {
                 if (full) direct_window<true, false>(wv, wout, w, zz, add, bit_lane, lo_rel, hi_rel);
                 else direct_window<false, false>(wv, wout, w, zz, add, bit_lane, lo_rel, hi_rel);
             } else {
@@ -1199,7 +1268,7 @@ __device__ __forceinline__ void decode_single_run(const W &wv, uint64_t desc, ui
             else linear_window<false>(wv, wout, base, step, idx0, lo_rel, hi_rel);
         }
     }
-    if (kind == KIND_PATCHED_BASE) {
+    if (kind == KIND_PATCHED_BASE && !patch_ahead) {
         __builtin_amdgcn_s_waitcnt(0);  // the unpatched values are written
         apply_patches(wv, desc, base, aux, run_out);
     }
@@ -1762,10 +1831,14 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
     // loads that bypass the caches would all queue at the one memory channel that holds it)
     if (MODE == MODE_VALUES && flags != nullptr) aborted = *flags;
     __shared__ uint32_t marks[VAL_WAVES][WINDOW / 32];
+    // (the variant that writes the values of long runs is the one that meets whole PatchedBase runs)
+    constexpr bool PATCH_AHEAD = MODE == MODE_VALUES && !SHORT;
+    __shared__ uint32_t patch_tab[PATCH_AHEAD ? VAL_WAVES : 1][PATCH_AHEAD ? PATCH_TAB_WORDS : 1];
     WaveOf<MODE> wv;
     wv.s = s;
     wv.lds = stage[wave];
     wv.marks = marks[wave];
+    wv.patch_tab = PATCH_AHEAD ? patch_tab[wave] : nullptr;
     wv.out = out;
     wv.num_values = num_values;
     wv.len = len;
@@ -1897,6 +1970,7 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel
     wv.s = s;
     wv.lds = stage[wave];
     wv.marks = nullptr;  // (only the variant for short runs uses them)
+    wv.patch_tab = nullptr;
     wv.out = out;
     wv.num_values = num_values;
     wv.len = len;
