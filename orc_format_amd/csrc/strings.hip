@@ -399,6 +399,42 @@ __global__ __launch_bounds__(256) void dictionary_chunk_sums_kernel(
     if (lane == 0) chunk_sums[i >> 6] = l;
 }
 
+// The same with the entries' lengths in LDS, for a dictionary whose offsets fit there: the two
+// look-ups per value at random places of the offsets array otherwise keep the texture unit busy
+// longer than the indices take to stream in.  Every workgroup builds the table once (checking the
+// offsets as it does) and then takes chunks of 64 values in turn.
+__global__ __launch_bounds__(256) void dictionary_chunk_sums_lds_kernel(
+    const int64_t *__restrict__ dict_offsets, uint32_t dict_size, uint64_t dict_total,
+    const int64_t *__restrict__ indices, uint64_t n, uint64_t *__restrict__ chunk_sums,
+    uint32_t *__restrict__ error_flag) {
+    extern __shared__ uint32_t l_len[];  // [dict_size]
+    for (uint32_t k = threadIdx.x; k < dict_size; k += blockDim.x) {
+        const uint64_t b = (uint64_t)dict_offsets[k], e = (uint64_t)dict_offsets[k + 1];
+        uint32_t l = 0;
+        if (e < b || e > dict_total) atomicOr(error_flag, 2u);  // not offsets of dict_bytes
+        else l = (uint32_t)(e - b);  // dict_total is below 2^32 here
+        l_len[k] = l;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t n_chunks = (n + 63) / 64;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks;
+         chunk += (uint64_t)gridDim.x * 4) {
+        const uint64_t i = chunk * 64 + lane;
+        uint64_t l = 0;
+        if (i < n) {
+            const uint64_t idx = (uint64_t)indices[i];
+            if (idx >= dict_size) atomicOr(error_flag, 1u);  // deserialize.rs:162 -> OutOfSpec
+            else l = l_len[idx];
+        }
+        for (int d = 32; d >= 1; d >>= 1) {  // 64 lengths below 2^32 each: the sum cannot wrap
+            const uint32_t lo = __shfl_xor((uint32_t)l, d), hi = __shfl_xor((uint32_t)(l >> 32), d);
+            l += ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 0) chunk_sums[chunk] = l;
+    }
+}
+
 // len bytes from src to dst, both of any alignment: single bytes up to a 4-byte boundary of the
 // destination, then whole dwords -- each put together from the two aligned source dwords it
 // straddles -- then the last bytes.  No source dword past `last_word` (the aligned dword that
@@ -529,8 +565,15 @@ hipError_t launch_dictionary_chunk_sums(hipStream_t st, const int64_t *dict_offs
                                         uint64_t dict_total, const int64_t *indices, uint64_t n,
                                         uint64_t *chunk_sums, uint32_t *error_flag) {
     if (n == 0) return hipSuccess;
-    dictionary_chunk_sums_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(
-        dict_offsets, dict_size, dict_total, indices, n, chunk_sums, error_flag);
+    const uint64_t chunks = (n + 63) / 64;
+    if (dict_size * 4 <= DG_DICT_LDS && dict_total < 0xFFFFFFFFull && chunks >= 256) {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((chunks + 3) / 4, 256 * 8);
+        dictionary_chunk_sums_lds_kernel<<<blocks, 256, (size_t)dict_size * 4, st>>>(
+            dict_offsets, (uint32_t)dict_size, dict_total, indices, n, chunk_sums, error_flag);
+    } else {
+        dictionary_chunk_sums_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(
+            dict_offsets, dict_size, dict_total, indices, n, chunk_sums, error_flag);
+    }
     return hipGetLastError();
 }
 

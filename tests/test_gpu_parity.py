@@ -444,12 +444,23 @@ def test_dictionary_gather_shapes(gpu, oracle, shape):
         lens = rng.integers(0, 3, size=200)          # many empty entries
     doff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     dbytes = rng.integers(0, 256, size=int(doff[-1]), dtype=np.uint8).tobytes()
-    for n in (1, 63, 64, 65, 1000, 20_001):
+    # (from 16 384 values on, the sums of a dictionary whose offsets fit LDS come from the table there)
+    for n in (1, 63, 64, 65, 1000, 20_001, 300_001):
         idx = rng.integers(0, lens.size, size=n)
         rc, o_ref, b_ref = oracle.string_dictionary(doff, dbytes, idx)
         assert rc == 0
         rc, o_gpu, b_gpu = gpu.string_dictionary(doff, dbytes, idx)
         assert rc == 0 and (o_gpu == o_ref).all() and b_gpu.tobytes() == b_ref.tobytes(), n
+    # an index past the dictionary, and offsets that do not describe its bytes, at that size too
+    idx = rng.integers(0, lens.size, size=50_000)
+    idx[31_337] = lens.size
+    assert gpu.string_dictionary(doff, dbytes, idx)[0] == 1
+    assert oracle.string_dictionary(doff, dbytes, idx)[0] == 1
+    idx[31_337] = 0
+    bad = doff.copy()
+    if lens.size > 3 and doff[2] < doff[-1]:
+        bad[2] = doff[-1] + 5
+        assert gpu.string_dictionary(bad, dbytes, idx)[0] != 0
 
 
 # ---- device pointers and larger sizes ----------------------------------------------------------
