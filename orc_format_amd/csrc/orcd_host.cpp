@@ -4,10 +4,14 @@
 // (src/read/mod.rs:46-159, src/read/column.rs:11-79) with a hand-written reader for the handful of
 // protobuf messages involved (src/proto.rs:89-99, 113-164, 166-217, 236-278).  No GPU code here.
 #include <stdio.h>
+#include <stdlib.h>
 #include <unistd.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <new>
+#include <thread>
 #include <string>
 #include <vector>
 #include <utility>
@@ -182,50 +186,118 @@ namespace {
 // receives (offset of the chunk header in src, offset of its first byte in out - out's size on
 // entry).  A header or chunk that reaches past the end, or bytes that do not inflate: the
 // reference panics or fails with Error::Decompression -- ORCD_DECOMPRESSION here.
+// One compressed chunk (raw deflate, src[0, len)) appended to `out`; it may not grow past `block`.
+int inflate_one(const uint8_t *src, size_t len, uint64_t block, std::vector<uint8_t> &out) {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) return ORCD_NO_MEMORY;
+    zs.next_in = const_cast<Bytef *>(src);
+    zs.avail_in = (uInt)len;
+    int zrc = Z_OK;
+    const size_t chunk_at = out.size();
+    while (zrc != Z_STREAM_END) {
+        const size_t at = out.size();
+        // (no chunk decompresses to more than the file's compression block size: damaged
+        // bytes must not make this grow without bound)
+        if (at - chunk_at > block) {
+            zrc = Z_DATA_ERROR;
+            break;
+        }
+        const size_t room = std::min<size_t>(std::max<size_t>(4 * len, 1 << 16), (size_t)(block - (at - chunk_at)) + 1);
+        out.resize(at + room);
+        zs.next_out = out.data() + at;
+        zs.avail_out = (uInt)room;
+        zrc = inflate(&zs, Z_NO_FLUSH);
+        out.resize(at + (room - zs.avail_out));
+        if (zrc != Z_OK && zrc != Z_STREAM_END) break;        // data error, or input exhausted
+        if (zrc == Z_OK && zs.avail_in == 0 && zs.avail_out != 0) break;  // ends before the stream does
+    }
+    inflateEnd(&zs);
+    return zrc == Z_STREAM_END ? ORCD_OK : ORCD_DECOMPRESSION;
+}
+
+// Chunks are independent deflate streams, and inflating is by far the slowest thing the host does
+// for a compressed file: streams of INFLATE_PARALLEL_MIN compressed bytes and more are inflated
+// by several threads, each chunk into a buffer of its own, and put together afterwards.
+constexpr size_t INFLATE_PARALLEL_MIN = 1u << 20;
+constexpr unsigned INFLATE_MAX_THREADS = 16;
+
 int inflate_chunks(const uint8_t *src, size_t n, uint64_t block, std::vector<uint8_t> &out,
                    std::vector<std::pair<uint64_t, uint64_t>> *chunks) {
     const size_t out0 = out.size();
-    size_t pos = 0;
     if (block > (1ull << 30)) block = 1ull << 30;  // (whatever the PostScript claims)
-    while (pos < n) {
+    // the chunk headers first: where each chunk lies and whether it is stored as it is
+    struct Chunk {
+        size_t header, at, len;
+        bool original;
+    };
+    std::vector<Chunk> list;
+    size_t compressed_bytes = 0;
+    for (size_t pos = 0; pos < n;) {
         if (n - pos < 3) return ORCD_DECOMPRESSION;
         const uint32_t h = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
-        const bool original = h & 1;
         const size_t len = h >> 1;
-        if (chunks) chunks->push_back({(uint64_t)pos, (uint64_t)(out.size() - out0)});
-        pos += 3;
-        if (len > n - pos) return ORCD_DECOMPRESSION;
-        if (original) {
-            out.insert(out.end(), src + pos, src + pos + len);
-        } else if (len) {
-            z_stream zs;
-            memset(&zs, 0, sizeof(zs));
-            if (inflateInit2(&zs, -15) != Z_OK) return ORCD_NO_MEMORY;
-            zs.next_in = const_cast<Bytef *>(src + pos);
-            zs.avail_in = (uInt)len;
-            int zrc = Z_OK;
-            const size_t chunk_at = out.size();
-            while (zrc != Z_STREAM_END) {
-                const size_t at = out.size();
-                // (no chunk decompresses to more than the file's compression block size: damaged
-                // bytes must not make this grow without bound)
-                if (at - chunk_at > block) {
-                    zrc = Z_DATA_ERROR;
-                    break;
-                }
-                const size_t room = std::min<size_t>(std::max<size_t>(4 * len, 1 << 16), (size_t)(block - (at - chunk_at)) + 1);
-                out.resize(at + room);
-                zs.next_out = out.data() + at;
-                zs.avail_out = (uInt)room;
-                zrc = inflate(&zs, Z_NO_FLUSH);
-                out.resize(at + (room - zs.avail_out));
-                if (zrc != Z_OK && zrc != Z_STREAM_END) break;        // data error, or input exhausted
-                if (zrc == Z_OK && zs.avail_in == 0 && zs.avail_out != 0) break;  // ends before the stream does
+        if (len > n - pos - 3) return ORCD_DECOMPRESSION;
+        list.push_back({pos, pos + 3, len, (h & 1) != 0});
+        if (!(h & 1)) compressed_bytes += len;
+        pos += 3 + len;
+    }
+    unsigned n_threads = 1;
+    size_t parallel_min = INFLATE_PARALLEL_MIN;
+    if (const char *e = getenv("ORCD_INFLATE_PARALLEL_MIN"))  // (tests: the threaded way on small files)
+        if (*e) parallel_min = (size_t)strtoull(e, nullptr, 10);
+    if (compressed_bytes >= parallel_min && list.size() > 1) {
+        n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), INFLATE_MAX_THREADS);
+        n_threads = (unsigned)std::min<size_t>(n_threads, list.size());
+    }
+    if (n_threads <= 1) {
+        for (const Chunk &c : list) {
+            if (chunks) chunks->push_back({(uint64_t)c.header, (uint64_t)(out.size() - out0)});
+            if (c.original) {
+                out.insert(out.end(), src + c.at, src + c.at + c.len);
+            } else if (c.len) {
+                const int rc = inflate_one(src + c.at, c.len, block, out);
+                if (rc != ORCD_OK) return rc;
             }
-            inflateEnd(&zs);
-            if (zrc != Z_STREAM_END) return ORCD_DECOMPRESSION;
         }
-        pos += len;
+        return ORCD_OK;
+    }
+    // the threads take the chunks in turn
+    std::vector<std::vector<uint8_t>> plain(list.size());
+    std::vector<int> status(list.size(), ORCD_OK);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    auto work = [&]() {
+        for (size_t k; (k = next.fetch_add(1)) < list.size() && !failed;) {
+            const Chunk &c = list[k];
+            if (c.original || c.len == 0) continue;  // copied below, straight from the source
+            try {
+                status[k] = inflate_one(src + c.at, c.len, block, plain[k]);
+            } catch (const std::bad_alloc &) {
+                status[k] = ORCD_NO_MEMORY;
+            }
+            if (status[k] != ORCD_OK) failed = true;
+        }
+    };
+    std::vector<std::thread> threads;
+    for (unsigned i = 1; i < n_threads; i++) {
+        try {
+            threads.emplace_back(work);
+        } catch (...) {
+            break;  // as many as can be had; this thread works too
+        }
+    }
+    work();
+    for (auto &th : threads) th.join();
+    for (size_t k = 0; k < list.size(); k++)  // the first failure in stream order, as a serial walk reports it
+        if (status[k] != ORCD_OK) return status[k];
+    size_t total = 0;
+    for (size_t k = 0; k < list.size(); k++) total += list[k].original ? list[k].len : plain[k].size();
+    out.reserve(out.size() + total);
+    for (size_t k = 0; k < list.size(); k++) {
+        if (chunks) chunks->push_back({(uint64_t)list[k].header, (uint64_t)(out.size() - out0)});
+        if (list[k].original) out.insert(out.end(), src + list[k].at, src + list[k].at + list[k].len);
+        else out.insert(out.end(), plain[k].begin(), plain[k].end());
     }
     return ORCD_OK;
 }

@@ -279,3 +279,59 @@ def test_compression_chunks(tmp_path):
         read.read_stripe_column(md2, 0, read.read_stripe_footer(md2, 0), 1)
     assert e.value.variant == "Decompression"
     _ = (zlib, rng)
+
+
+def test_compression_chunks_inflated_by_several_threads(tmp_path, monkeypatch):
+    """Streams of many compression chunks are inflated by several host threads (chunks are
+    independent deflate streams, decompress/mod.rs:60-80): the same bytes and the same ROW_INDEX
+    positions as the one-thread way, and a damaged chunk is the same error."""
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    rng = np.random.default_rng(9)
+    rows = 400_000
+    table = pa.table({
+        "a": pa.array(np.cumsum(rng.integers(1, 50, size=rows))),
+        "s": pa.array(["value-%d" % k for k in rng.integers(0, 3000, size=rows)]),
+    })
+    path = str(tmp_path / "zt.orc")
+    orc.write_table(table, path, compression="zlib", compression_block_size=65536)
+
+    def snapshot():
+        md = read.read_metadata(path)
+        out = []
+        for si in range(len(md.stripes)):
+            footer = read.read_stripe_footer(md, si)
+            for col in (1, 2):
+                column = read.read_stripe_column(md, si, footer, col)
+                for kind in (StreamKind.Present, StreamKind.Data, StreamKind.Length, StreamKind.DictionaryData):
+                    try:
+                        out.append((si, col, int(kind), bytes(column.get_stream(kind)),
+                                    tuple(column.entry_points(kind))))
+                    except OrcError:
+                        pass
+        return out
+    monkeypatch.setenv("ORCD_INFLATE_PARALLEL_MIN", "18446744073709551615")
+    serial = snapshot()
+    monkeypatch.setenv("ORCD_INFLATE_PARALLEL_MIN", "1")
+    threaded = snapshot()
+    assert len(serial) >= 3 and serial == threaded
+    assert sum(len(s[3]) for s in serial) > 1_000_000
+    # one damaged deflate stream in the middle of a column: Decompression either way
+    md = read.read_metadata(path)
+    with open(path, "rb") as f:
+        image = bytearray(f.read())
+    st = md.stripes[0]
+    at = st.offset + st.index_length + st.data_length // 2
+    image[at:at + 64] = bytes(64)
+    for threshold in ("1", "18446744073709551615"):
+        monkeypatch.setenv("ORCD_INFLATE_PARALLEL_MIN", threshold)
+        md2 = read.read_metadata(bytes(image))
+        footer = read.read_stripe_footer(md2, 0)
+        seen = []
+        for col in (1, 2):
+            try:
+                read.read_stripe_column(md2, 0, footer, col)
+                seen.append("ok")
+            except OrcError as e:
+                seen.append(e.variant)
+        assert "Decompression" in seen

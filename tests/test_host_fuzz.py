@@ -119,12 +119,14 @@ def test_reader_under_address_and_undefined_behaviour_sanitizers(golden_dir, tmp
         [gxx, "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
          "-static-libasan", "-I", os.path.join(root, "include"),
          os.path.join(root, "orc_format_amd", "csrc", "orcd_host.cpp"),
-         os.path.join(root, "tests", "host_fuzz_driver.cpp"), "-o", exe, "-lz"],
+         os.path.join(root, "tests", "host_fuzz_driver.cpp"), "-o", exe, "-lz", "-pthread"],
         capture_output=True, text=True, timeout=300)
     if build.returncode != 0 and "asan" in build.stderr.lower():
         pytest.skip("the sanitizer runtime is not installed")
     assert build.returncode == 0, build.stderr[-2000:]
-    run = subprocess.run([exe] + [os.path.join(golden_dir, f) for f in FILES], capture_output=True, text=True,
-                         timeout=300)
-    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
-    assert "opened" in run.stdout
+    # once the plain way, once with every compressed stream inflated by several threads
+    for env in ({}, {"ORCD_INFLATE_PARALLEL_MIN": "1"}):
+        run = subprocess.run([exe] + [os.path.join(golden_dir, f) for f in FILES], capture_output=True, text=True,
+                             timeout=300, env=dict(os.environ, **env))
+        assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+        assert "opened" in run.stdout
