@@ -1953,7 +1953,7 @@ __device__ __forceinline__ uint32_t code_from_width(uint32_t w) {
 
 __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries, uint32_t n_seg,
-    uint32_t n_win, uint64_t num_values, int is_signed, int64_t *__restrict__ out,
+    uint32_t n_win, uint32_t runs_hint, uint64_t num_values, int is_signed, int64_t *__restrict__ out,
     uint32_t *__restrict__ flag) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[VAL_WAVES][STAGE_WORDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1986,8 +1986,14 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel
     // second entry point over the size of the first run, which must be a Direct run of 512 values
     // like all the others (two bytes that every wavefront finds in cache).  All segments but the
     // last hold that many windows, the last one the rest (at least one).
+    // (runs_hint: the counts of windows and entry points leave one possibility -- true of any column
+    // of many segments -- and the host passes it; the checks below do not care where the number
+    // comes from, and a wavefront that need not work it out starts on its bytes a round trip sooner)
     uint32_t runs_per_seg = n_win;
-    if (n_seg > 1) {
+    if (n_seg > 1 && runs_hint != 0) {
+        runs_per_seg = runs_hint;
+        if ((uint64_t)runs_per_seg * (n_seg - 1) >= n_win) return fail();
+    } else if (n_seg > 1) {
         const uint64_t d0 = readfirstlane64(entries[1]);
         if (len < 2 || d0 > 0xFFFFFFFFull) return fail();
         const uint32_t h0 = __builtin_amdgcn_readfirstlane((uint32_t)s[0]);
@@ -2064,7 +2070,9 @@ hipError_t launch_rlev2_strided_values(hipStream_t st, const uint8_t *stream, ui
                                        ScanTotals *host_totals, uint32_t stamp) {
     if (n_win == 0 || n_seg == 0 || (((uintptr_t)out) & 15)) return hipErrorInvalidValue;
     const uint32_t blocks = (n_win + VAL_WAVES - 1) / VAL_WAVES;
-    rlev2_strided_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, entries, n_seg, n_win,
+    uint32_t r_lo = 0, r_hi = 0, runs_hint = 0;
+    if (rlev2_regular_plan_shape(n_seg, n_win, &r_lo, &r_hi) && r_lo == r_hi) runs_hint = r_lo;
+    rlev2_strided_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, entries, n_seg, n_win, runs_hint,
                                                                   num_values, is_signed, out, flag);
     spec_publish_kernel<<<1, 64, 0, st>>>(flag, host_totals, stamp);
     return hipGetLastError();
