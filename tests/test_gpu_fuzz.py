@@ -125,3 +125,48 @@ def test_string_lengths_versus_data(gpu, oracle):
             assert rc_cpu == rc_gpu, (case, data_len, rc_cpu, rc_gpu)
             if rc_cpu == 0:
                 assert (off == off_ref).all() and out.tobytes() == out_ref.tobytes()
+
+
+def test_speculative_paths_on_mutated_regular_columns(oracle):
+    """Columns of full runs with entry points -- what the strided and the plan-and-expand paths
+    take -- with bytes flipped, cut and appended: whatever a speculative path makes of them, a
+    decode that succeeds gives the oracle's values, damage that leaves the run headers where the
+    entry points say they are still decodes, and nothing faults."""
+    from orc_format_amd import Context
+    from orc_format_amd.error import OrcError
+    rng = np.random.default_rng(17)
+    agreed = refused = 0
+    paths = set()
+    for case in range(120):
+        with Context(0) as ctx:   # a context of its own: no back-off carried over from the case before
+            signed = bool(case & 1)
+            kinds = [(1,), (3,), (1, 2, 3), (2,)][case % 4]
+            widths = [int(rng.choice(enc.WIDTHS[1:24]))] if case % 3 else None
+            n_runs = int(rng.integers(9, 60))
+            stream, expect, starts = enc.random_stream(rng, n_runs, signed, kinds=kinds, widths=widths,
+                                                       min_len=512, max_len=512)
+            entries = np.array(starts[::int(rng.integers(1, 12))], dtype=np.uint64)
+            for m in [stream] + _mutations(rng, stream, 4):
+                for n in {expect.size, expect.size - int(rng.integers(1, 600))}:
+                    rc_cpu, ref, _ = oracle.rlev2(m, n, signed)
+                    try:
+                        out = ctx.rlev2(m, n, signed, entries[entries < max(len(m), 1)] if len(m) else None)
+                        rc_gpu = 0
+                    except OrcError:
+                        out, rc_gpu = None, 1
+                    if rc_gpu == 0:
+                        assert rc_cpu == 0, (case, n, ctx.last_path())
+                        assert (out == ref).all(), (case, n, ctx.last_path())
+                        agreed += 1
+                        paths.add(ctx.last_path())
+                    else:
+                        refused += 1
+                        # entry points that are still run starts of the damaged stream hold, and
+                        # then the stream is as decodable as the oracle finds it
+                        if rc_cpu == 0:
+                            rc_r, runs_m = oracle.runs(m, n)
+                            offs = [r[3] for r in runs_m]
+                            used = [int(e) for e in entries if offs and int(e) <= offs[-1]]
+                            assert rc_r != 0 or not set(used) <= set(offs), (case, n, used[:5], offs[:5])
+    assert agreed > 200 and refused > 20
+    assert paths == {0, 1, 2}   # the general path, the strided kernel and the plan-and-expand path all answered
