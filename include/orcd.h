@@ -43,7 +43,7 @@ enum {
     ORCD_DECODE_FLOAT = 5,
     ORCD_DECOMPRESSION = 6,
     ORCD_INVALID_PROTO = 7,
-    ORCD_UNSUPPORTED = 100, /* the crate panics with todo!() here (e.g. codecs other than zlib) */
+    ORCD_UNSUPPORTED = 100, /* the crate panics with todo!() here (e.g. LZO-compressed files, RLE v1) */
     ORCD_HIP_ERROR = 101,
     ORCD_INVALID_ARGUMENT = 102,
     ORCD_NO_MEMORY = 103 /* host memory ran out inside the library */
@@ -305,8 +305,9 @@ typedef struct { /* proto::Stream, src/proto.rs:113-137, plus its resolved posit
  * file open for the later region reads.  Unlike the crate, a tail larger than 16 KiB is re-read
  * at its exact size instead of panicking.  Files of CompressionKind None and Zlib are read
  * (src/read/decompress/mod.rs:60-80: footers, stripe footers and streams as chains of compression
- * chunks, inflated on the host; broken chunks are ORCD_DECOMPRESSION); any other kind is
- * ORCD_UNSUPPORTED, where the crate panics. */
+ * chunks, decompressed on the host; broken chunks are ORCD_DECOMPRESSION), and, where the crate
+ * panics (:81), Snappy, LZ4 and Zstandard -- the latter two when the process can load the system's
+ * liblz4.so.1 / libzstd.so.1; LZO, an unknown kind or a missing library is ORCD_UNSUPPORTED. */
 int orcd_file_open(const char *path, orcd_file **file);
 /* Same, over a file image in host memory (borrowed: it must outlive the handle). */
 int orcd_file_open_memory(const uint8_t *bytes, size_t len, orcd_file **file);

@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
         if verbose and out:
             print(out.decode(), file=sys.stderr)
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [
-        "-pthread", "-lz", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
+        "-pthread", "-lz", "-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
     subprocess.check_call(link)
     return LIB
 

@@ -2475,7 +2475,6 @@ int orcd_decode_stripe(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
                        const uint32_t *columns, size_t n_columns, unsigned flags, orcd_column_data *out) try {
     if (!c || !file || !footer || (n_columns && (!columns || !out))) return ORCD_INVALID_ARGUMENT;
     for (size_t i = 0; i < n_columns; i++) memset(&out[i], 0, sizeof(out[i]));
-    if (orcd_file_compression(file) > 1) return ORCD_UNSUPPORTED;  // None and Zlib, as the reference
     DeviceGuard g(c->device);
     std::vector<std::unique_ptr<StripeJob>> jobs;
     for (size_t i = 0; i < n_columns; i++) jobs.emplace_back(new StripeJob(c));

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <unistd.h>
+#include <dlfcn.h>
 #include <string.h>
 
 #include <algorithm>
@@ -186,6 +187,126 @@ namespace {
 // receives (offset of the chunk header in src, offset of its first byte in out - out's size on
 // entry).  A header or chunk that reaches past the end, or bytes that do not inflate: the
 // reference panics or fails with Error::Decompression -- ORCD_DECOMPRESSION here.
+// ---- codecs beyond zlib ---------------------------------------------------------------------
+// The reference stops at zlib (decompress/mod.rs:81 is todo!() for the others); files in the
+// field are as often Snappy, LZ4 or Zstandard.  Their chunk framing is the same; the codecs are:
+// Snappy, decoded here (the format is a length and a series of literals and back-references);
+// LZ4 (raw blocks) and Zstandard (frames) through the system's liblz4 / libzstd when the
+// process can load them -- no headers are needed for the two calls used -- else ORCD_UNSUPPORTED.
+constexpr int COMP_NONE = 0, COMP_ZLIB = 1, COMP_SNAPPY = 2, COMP_LZO = 3, COMP_LZ4 = 4, COMP_ZSTD = 5;
+
+struct CodecLibs {
+    int (*lz4_decompress_safe)(const char *, char *, int, int) = nullptr;
+    size_t (*zstd_decompress)(void *, size_t, const void *, size_t) = nullptr;
+    unsigned (*zstd_is_error)(size_t) = nullptr;
+    CodecLibs() {
+        if (void *h = dlopen("liblz4.so.1", RTLD_NOW | RTLD_LOCAL))
+            lz4_decompress_safe = (int (*)(const char *, char *, int, int))dlsym(h, "LZ4_decompress_safe");
+        if (void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL)) {
+            zstd_decompress = (size_t (*)(void *, size_t, const void *, size_t))dlsym(h, "ZSTD_decompress");
+            zstd_is_error = (unsigned (*)(size_t))dlsym(h, "ZSTD_isError");
+        }
+    }
+};
+const CodecLibs &codec_libs() {
+    static const CodecLibs libs;  // loaded once, on first use
+    return libs;
+}
+
+bool codec_available(int kind) {
+    if (kind == COMP_NONE || kind == COMP_ZLIB || kind == COMP_SNAPPY) return true;
+    if (kind == COMP_LZ4) return codec_libs().lz4_decompress_safe != nullptr;
+    if (kind == COMP_ZSTD) return codec_libs().zstd_decompress != nullptr && codec_libs().zstd_is_error != nullptr;
+    return false;
+}
+
+// Snappy, raw format: a varint with the decompressed length, then elements whose tag byte's low
+// two bits say literal (00: length in the tag or in 1..4 bytes after it) or copy (01: 11-bit
+// offset, length 4..11; 10: 16-bit offset; 11: 32-bit offset; lengths 1..64).  Copies may overlap
+// their own output.  Appends to `out`, at most `block` bytes.
+int snappy_one(const uint8_t *src, size_t len, uint64_t block, std::vector<uint8_t> &out) {
+    size_t p = 0;
+    uint64_t want = 0;
+    for (int shift = 0;; shift += 7) {
+        if (p >= len || shift > 28) return ORCD_DECOMPRESSION;
+        const uint8_t b = src[p++];
+        want |= (uint64_t)(b & 0x7F) << shift;
+        if (!(b & 0x80)) break;
+    }
+    if (want > block) return ORCD_DECOMPRESSION;
+    const size_t at = out.size();
+    out.resize(at + want);
+    uint8_t *dst = out.data() + at;
+    size_t o = 0;
+    while (p < len) {
+        const uint8_t tag = src[p++];
+        if ((tag & 3) == 0) {
+            size_t n = (size_t)(tag >> 2) + 1;
+            if (n > 60) {
+                const size_t extra = n - 60;  // 1..4 bytes of length
+                if (len - p < extra) return ORCD_DECOMPRESSION;
+                n = 0;
+                for (size_t i = 0; i < extra; i++) n |= (size_t)src[p + i] << (8 * i);
+                n += 1;
+                p += extra;
+            }
+            if (n > len - p || n > want - o) return ORCD_DECOMPRESSION;
+            memcpy(dst + o, src + p, n);
+            p += n;
+            o += n;
+        } else {
+            size_t n, off;
+            if ((tag & 3) == 1) {
+                if (len - p < 1) return ORCD_DECOMPRESSION;
+                n = (size_t)((tag >> 2) & 7) + 4;
+                off = ((size_t)(tag >> 5) << 8) | src[p];
+                p += 1;
+            } else if ((tag & 3) == 2) {
+                if (len - p < 2) return ORCD_DECOMPRESSION;
+                n = (size_t)(tag >> 2) + 1;
+                off = (size_t)src[p] | ((size_t)src[p + 1] << 8);
+                p += 2;
+            } else {
+                if (len - p < 4) return ORCD_DECOMPRESSION;
+                n = (size_t)(tag >> 2) + 1;
+                off = (size_t)src[p] | ((size_t)src[p + 1] << 8) | ((size_t)src[p + 2] << 16) | ((size_t)src[p + 3] << 24);
+                p += 4;
+            }
+            if (off == 0 || off > o || n > want - o) return ORCD_DECOMPRESSION;
+            for (size_t i = 0; i < n; i++) dst[o + i] = dst[o + i - off];  // (may overlap itself)
+            o += n;
+        }
+    }
+    return o == want ? ORCD_OK : ORCD_DECOMPRESSION;
+}
+
+// One LZ4 block / one Zstandard frame: neither says in ORC how large it gets, but none may exceed
+// the file's compression block size.
+int lz4_one(const uint8_t *src, size_t len, uint64_t block, std::vector<uint8_t> &out) {
+    if (len > 0x7FFFFFFFull || block > 0x7FFFFFFFull) return ORCD_DECOMPRESSION;
+    const size_t at = out.size();
+    out.resize(at + block);
+    const int got = codec_libs().lz4_decompress_safe((const char *)src, (char *)out.data() + at, (int)len, (int)block);
+    if (got < 0) {
+        out.resize(at);
+        return ORCD_DECOMPRESSION;
+    }
+    out.resize(at + (size_t)got);
+    return ORCD_OK;
+}
+
+int zstd_one(const uint8_t *src, size_t len, uint64_t block, std::vector<uint8_t> &out) {
+    const size_t at = out.size();
+    out.resize(at + block);
+    const size_t got = codec_libs().zstd_decompress(out.data() + at, block, src, len);
+    if (codec_libs().zstd_is_error(got)) {
+        out.resize(at);
+        return ORCD_DECOMPRESSION;
+    }
+    out.resize(at + got);
+    return ORCD_OK;
+}
+
 // One compressed chunk (raw deflate, src[0, len)) appended to `out`; it may not grow past `block`.
 int inflate_one(const uint8_t *src, size_t len, uint64_t block, std::vector<uint8_t> &out) {
     z_stream zs;
@@ -222,7 +343,17 @@ int inflate_one(const uint8_t *src, size_t len, uint64_t block, std::vector<uint
 constexpr size_t INFLATE_PARALLEL_MIN = 1u << 20;
 constexpr unsigned INFLATE_MAX_THREADS = 16;
 
-int inflate_chunks(const uint8_t *src, size_t n, uint64_t block, std::vector<uint8_t> &out,
+int decompress_one(int codec, const uint8_t *src, size_t len, uint64_t block, std::vector<uint8_t> &out) {
+    switch (codec) {
+    case COMP_ZLIB: return inflate_one(src, len, block, out);
+    case COMP_SNAPPY: return snappy_one(src, len, block, out);
+    case COMP_LZ4: return lz4_one(src, len, block, out);
+    case COMP_ZSTD: return zstd_one(src, len, block, out);
+    default: return ORCD_UNSUPPORTED;
+    }
+}
+
+int inflate_chunks(int codec, const uint8_t *src, size_t n, uint64_t block, std::vector<uint8_t> &out,
                    std::vector<std::pair<uint64_t, uint64_t>> *chunks) {
     const size_t out0 = out.size();
     if (block > (1ull << 30)) block = 1ull << 30;  // (whatever the PostScript claims)
@@ -256,7 +387,7 @@ int inflate_chunks(const uint8_t *src, size_t n, uint64_t block, std::vector<uin
             if (c.original) {
                 out.insert(out.end(), src + c.at, src + c.at + c.len);
             } else if (c.len) {
-                const int rc = inflate_one(src + c.at, c.len, block, out);
+                const int rc = decompress_one(codec, src + c.at, c.len, block, out);
                 if (rc != ORCD_OK) return rc;
             }
         }
@@ -272,7 +403,7 @@ int inflate_chunks(const uint8_t *src, size_t n, uint64_t block, std::vector<uin
             const Chunk &c = list[k];
             if (c.original || c.len == 0) continue;  // copied below, straight from the source
             try {
-                status[k] = inflate_one(src + c.at, c.len, block, plain[k]);
+                status[k] = decompress_one(codec, src + c.at, c.len, block, plain[k]);
             } catch (const std::bad_alloc &) {
                 status[k] = ORCD_NO_MEMORY;
             }
@@ -333,7 +464,7 @@ int parse_tail(orcd_file *f) {
     }
     if (!has_footer_length) return ORCD_OUT_OF_SPEC;  // src/read/mod.rs:73
     // CompressionKind None and Zlib, as the reference (decompress/mod.rs:60-82: the rest is todo!())
-    if (f->compression != 0 && f->compression != 1) return ORCD_UNSUPPORTED;
+    if (!codec_available(f->compression)) return ORCD_UNSUPPORTED;  // LZO, an unknown kind, or a codec library that is not there
     uint64_t need;
     if (!add3_ok(1 + ps_len, footer_length, metadata_length, need) || need > s.len) return ORCD_OUT_OF_SPEC;
     if (need > tail_len) {  // the crate panics here; re-read the tail at its exact size
@@ -394,7 +525,7 @@ int plain_section(const orcd_file *f, const uint8_t *p, size_t n, std::vector<ui
         out.assign(p, p + n);
         return ORCD_OK;
     }
-    return inflate_chunks(p, n, f->compression_block, out, nullptr);
+    return inflate_chunks(f->compression, p, n, f->compression_block, out, nullptr);
 }
 
 int parse_stripe_footer(const std::vector<uint8_t> &buf, orcd_stripe_footer *out) {
@@ -696,7 +827,7 @@ int orcd_read_stripe_column(orcd_file *f, size_t stripe, const orcd_stripe_foote
             while (plain.size() & 15) plain.push_back(0);  // streams start 16-byte aligned
             col->plain_off.push_back(plain.size());
             col->chunks.emplace_back();
-            const int rc = inflate_chunks(col->data.data() + start2, (size_t)s.length, f->compression_block, plain, &col->chunks.back());
+            const int rc = inflate_chunks(f->compression, col->data.data() + start2, (size_t)s.length, f->compression_block, plain, &col->chunks.back());
             if (rc != ORCD_OK) {
                 delete col;
                 return rc;

@@ -335,3 +335,63 @@ def test_compression_chunks_inflated_by_several_threads(tmp_path, monkeypatch):
             except OrcError as e:
                 seen.append(e.variant)
         assert "Decompression" in seen
+
+
+@pytest.mark.parametrize("codec", ["snappy", "lz4", "zstd"])
+def test_other_codecs_give_the_streams_of_the_uncompressed_file(tmp_path, codec, monkeypatch):
+    """Snappy (decoded by the library itself), LZ4 and Zstandard (through the system's liblz4 /
+    libzstd) -- codecs the reference leaves at todo!() (decompress/mod.rs:81) -- behind the same
+    chunk framing as zlib (decompress/mod.rs:9-17): every stream of a compressed file holds the
+    bytes of its uncompressed twin, ROW_INDEX positions translate to the same offsets, and a
+    damaged chunk is Error::Decompression."""
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    rng = np.random.default_rng(31)
+    rows = 120_000
+    table = pa.table({
+        "a": pa.array(np.cumsum(rng.integers(1, 50, size=rows))),
+        "b": pa.array(rng.integers(-5, 5, size=rows), mask=rng.random(rows) < 0.1),
+        "s": pa.array(["value-%d" % k for k in rng.integers(0, 3000, size=rows)]),
+        "r": pa.array(rng.integers(0, 2**62, size=rows)),       # does not compress: stored chunks
+    })
+    plain_path, comp_path = str(tmp_path / "p.orc"), str(tmp_path / "c.orc")
+    orc.write_table(table, plain_path, compression="uncompressed")
+    orc.write_table(table, comp_path, compression=codec, compression_block_size=65536)
+
+    def snapshot(path):
+        md = read.read_metadata(path)
+        out = []
+        for si in range(len(md.stripes)):
+            footer = read.read_stripe_footer(md, si)
+            for col in range(1, 5):
+                column = read.read_stripe_column(md, si, footer, col)
+                for kind in (StreamKind.Present, StreamKind.Data, StreamKind.Length, StreamKind.DictionaryData):
+                    try:
+                        out.append((si, col, int(kind), bytes(column.get_stream(kind)),
+                                    tuple(int(e) for e in column.entry_points(kind))))
+                    except OrcError:
+                        pass
+        return md, out
+    md_p, plain = snapshot(plain_path)
+    for threshold in ("18446744073709551615", "1"):   # one thread, several threads
+        monkeypatch.setenv("ORCD_INFLATE_PARALLEL_MIN", threshold)
+        md_c, comp = snapshot(comp_path)
+        assert md_c.number_of_rows == md_p.number_of_rows == rows
+        assert len(comp) == len(plain) >= 6
+        assert comp == plain
+    # damage in the middle of the data area
+    with open(comp_path, "rb") as f:
+        image = bytearray(f.read())
+    st = md_c.stripes[0]
+    at = st.offset + st.index_length + st.data_length // 3
+    image[at:at + 200] = bytes(rng.integers(0, 256, size=200, dtype=np.uint8))
+    md2 = read.read_metadata(bytes(image))
+    footer = read.read_stripe_footer(md2, 0)
+    seen = []
+    for col in range(1, 5):
+        try:
+            read.read_stripe_column(md2, 0, footer, col)
+            seen.append("ok")
+        except OrcError as e:
+            seen.append(e.variant)
+    assert set(seen) <= {"ok", "Decompression"} and "Decompression" in seen or seen.count("ok") == 4

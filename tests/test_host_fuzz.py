@@ -119,7 +119,7 @@ def test_reader_under_address_and_undefined_behaviour_sanitizers(golden_dir, tmp
         [gxx, "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
          "-static-libasan", "-I", os.path.join(root, "include"),
          os.path.join(root, "orc_format_amd", "csrc", "orcd_host.cpp"),
-         os.path.join(root, "tests", "host_fuzz_driver.cpp"), "-o", exe, "-lz", "-pthread"],
+         os.path.join(root, "tests", "host_fuzz_driver.cpp"), "-o", exe, "-lz", "-ldl", "-pthread"],
         capture_output=True, text=True, timeout=300)
     if build.returncode != 0 and "asan" in build.stderr.lower():
         pytest.skip("the sanitizer runtime is not installed")
