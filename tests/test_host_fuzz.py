@@ -124,9 +124,23 @@ def test_reader_under_address_and_undefined_behaviour_sanitizers(golden_dir, tmp
     if build.returncode != 0 and "asan" in build.stderr.lower():
         pytest.skip("the sanitizer runtime is not installed")
     assert build.returncode == 0, build.stderr[-2000:]
+    files = [os.path.join(golden_dir, f) for f in FILES]
+    # (files of the other codecs, written here: damaged Snappy elements, LZ4 blocks and Zstandard frames)
+    try:
+        import pyarrow as pa
+        import pyarrow.orc as orc
+        rng = np.random.default_rng(2)
+        table = pa.table({"a": pa.array(np.cumsum(rng.integers(1, 9, size=3000))),
+                          "s": pa.array(["w%d" % k for k in rng.integers(0, 40, size=3000)])})
+        for codec in ("snappy", "lz4", "zstd"):
+            path = str(tmp_path / ("fuzz_%s.orc" % codec))
+            orc.write_table(table, path, compression=codec, compression_block_size=65536)
+            files.append(path)
+    except ImportError:
+        pass
     # once the plain way, once with every compressed stream inflated by several threads
     for env in ({}, {"ORCD_INFLATE_PARALLEL_MIN": "1"}):
-        run = subprocess.run([exe] + [os.path.join(golden_dir, f) for f in FILES], capture_output=True, text=True,
+        run = subprocess.run([exe] + files, capture_output=True, text=True,
                              timeout=300, env=dict(os.environ, **env))
         assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
         assert "opened" in run.stdout
