@@ -424,9 +424,10 @@ int orcd_decode_stripe(orcd_ctx *ctx, orcd_file *file, size_t stripe,
  * copy to the device, with pinned chunks, reader threads and a stream of its own, so that they run
  * beside the decode of the stripe before.  The decode call for the same file, stripe and columns
  * then waits for those bytes instead of reading them; with other arguments it reads for itself and
- * the bytes read ahead stay until they are claimed or the context is destroyed.  At most two
- * stripes are kept ahead (further hints are ignored), served in the order given; compressed files
- * are not read ahead.  `file` and `footer` must stay open until the stripe has been decoded or the
+ * the bytes read ahead stay until they are claimed, pushed out or the context is destroyed.  At
+ * most two stripes are kept ahead, served in the order given: a further hint pushes out the oldest
+ * one if that has been read and never asked for, and is ignored otherwise; compressed files are
+ * not read ahead.  `file` and `footer` must stay open until the stripe has been decoded or the
  * context destroyed.  Returns what finding the region returns (ORCD_INVALID_COLUMN, ORCD_OUT_OF_SPEC
  * for a region outside the file, ...); a failed read shows when the stripe is decoded. */
 int orcd_stripe_prefetch(orcd_ctx *ctx, orcd_file *file, size_t stripe,

@@ -2510,12 +2510,22 @@ int orcd_stripe_prefetch(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd
     DeviceGuard g(c->device);
     ORCD_TRY(prefetch_start(c));
     Prefetcher *pf = c->prefetcher;
+    void *stale = nullptr;
     {
         std::lock_guard<std::mutex> lock(pf->m);
-        if (pf->jobs.size() >= Prefetcher::MAX_JOBS) return ORCD_OK;  // a hint: this one is not taken
         for (PrefetchJob *j : pf->jobs)
             if (j->file == file && j->stripe == stripe && j->file_off == file_off && j->len == len) return ORCD_OK;
+        if (pf->jobs.size() >= Prefetcher::MAX_JOBS) {
+            // full: the oldest stripe, if it was read and never asked for, makes room; otherwise
+            // this hint is not taken
+            PrefetchJob *oldest = pf->jobs.front();
+            if (!oldest->done) return ORCD_OK;
+            stale = oldest->d_buf;
+            pf->jobs.pop_front();
+            delete oldest;
+        }
     }
+    dev_free(c, stale);
     std::unique_ptr<PrefetchJob> job(new PrefetchJob());
     job->file = file;
     job->stripe = stripe;

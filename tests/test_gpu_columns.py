@@ -414,6 +414,14 @@ def test_stripes_read_ahead(tmp_path):
         ctx.stripe_prefetch(md, 0, footers[0], [2])
         same(ctx.decode_stripe(md, 0, footers[0], cols), want[0])
         same(ctx.decode_stripe(md, 0, footers[0], [2]), want[0][1:2])
+        # hints for stripes that are never decoded do not block later ones: the oldest makes room
+        import time
+        ctx.stripe_prefetch(md, 0, footers[0], cols)
+        ctx.stripe_prefetch(md, 1, footers[1], cols)
+        time.sleep(0.2)   # (both read by now)
+        ctx.stripe_prefetch(md, 4, footers[4], cols)
+        same(ctx.decode_stripe(md, 4, footers[4], cols), want[4])
+        same(ctx.decode_stripe(md, 1, footers[1], cols), want[1])
         # the same hint twice is one job
         ctx.stripe_prefetch(md, 1, footers[1], cols)
         ctx.stripe_prefetch(md, 1, footers[1], cols)
