@@ -140,6 +140,17 @@ int orcd_rlev2_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t n
                       const uint64_t *entry_points, size_t n_entries, int64_t *out,
                       unsigned flags);
 
+/* Integer RLE version 1: the DATA / LENGTH streams of files written as ORC 0.11 (ColumnEncoding
+ * DIRECT / DICTIONARY).  The crate does not decode it (README.md:23-25 lists RLE v1 as missing; its
+ * harness reads every integer stream as RLE v2, tests/it/deserialize.rs:48-82); the layout is the
+ * ORC v1 specification's -- runs of 3..130 values with a delta of -128..127, groups of 1..128
+ * literal varints.  Same contract as orcd_rlev2_decode: `num_values` values into out[], the same
+ * flags, `entry_points` at starts of runs or literal groups (a walk of one lane per segment: a
+ * stream without entry points is walked by a single lane). */
+int orcd_rlev1_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_values,
+                      const uint64_t *entry_points, size_t n_entries, int64_t *out,
+                      unsigned flags);
+
 /* orcd_rlev2_decode without any allocation.  No counterpart in the crate: this is for callers that
  * cannot allocate device memory at the point of the call -- code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc.  `stream`, `entry_points` and `out` are DEVICE

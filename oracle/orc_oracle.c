@@ -353,6 +353,41 @@ int orc_oracle_rlev2_runs(const uint8_t *stream, size_t len, size_t num_values,
  * byte, < 0 is (-control) literal bytes.  The run iterator of the crate over-counts runs by one
  * byte and never leaves a literal run (boolean_rle.rs:107-113,128); the lengths here are the ORC
  * specification's. */
+/* Integer RLE version 1 (ORC v1 specification, "Integer Run Length Encoding, version 1"; the
+ * reference lists it as not implemented, README.md:23-25).  A control byte 0..127 starts a run of
+ * control + 3 values: a signed delta byte, then the base as a varint (zigzag for signed streams,
+ * like every signed varint of rle_v2.rs:100-102), value i = base + i * delta (wrapping).  A control
+ * byte 128..255 starts 256 - control literal values, a varint each. */
+int orc_oracle_rlev1_i64(const uint8_t *stream, size_t len, size_t num_values, int is_signed,
+                         int64_t *out, size_t *consumed) {
+    reader r = {stream, len, 0};
+    size_t n = 0;
+    while (n < num_values) {
+        uint8_t control;
+        int rc = read_u8(&r, &control);
+        if (rc) return rc;
+        if (control < 128) {
+            uint8_t d;
+            uint64_t v;
+            if ((rc = read_u8(&r, &d))) return rc;
+            if ((rc = read_varint(&r, &v))) return rc;
+            const uint64_t base = is_signed ? (uint64_t)orc_oracle_zigzag(v) : v;
+            const uint64_t delta = (uint64_t)(int64_t)(int8_t)d;
+            const size_t count = (size_t)control + 3;
+            for (size_t i = 0; i < count && n < num_values; i++) out[n++] = (int64_t)(base + (uint64_t)i * delta);
+        } else {
+            const size_t count = 256 - (size_t)control;
+            for (size_t i = 0; i < count; i++) {   /* the whole group is read, as a run is */
+                uint64_t v;
+                if ((rc = read_varint(&r, &v))) return rc;
+                if (n < num_values) out[n++] = is_signed ? orc_oracle_zigzag(v) : (int64_t)v;
+            }
+        }
+    }
+    if (consumed) *consumed = r.pos;
+    return ORC_ORACLE_OK;
+}
+
 int orc_oracle_byte_rle(const uint8_t *stream, size_t len, size_t num_bytes, uint8_t *out,
                         size_t *consumed) {
     reader r = {stream, len, 0};

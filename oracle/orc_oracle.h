@@ -53,6 +53,12 @@ typedef struct {
 int orc_oracle_rlev2_i64(const uint8_t *stream, size_t len, size_t num_values, int is_signed,
                          int64_t *out, size_t *consumed);
 
+/* Integer RLE version 1 (ORC v1 specification; not in the reference, README.md:23-25): the same
+ * contract as orc_oracle_rlev2_i64 -- exactly `num_values` values, trailing bytes ignored, the
+ * last run or literal group is read whole and truncated. */
+int orc_oracle_rlev1_i64(const uint8_t *stream, size_t len, size_t num_values, int is_signed,
+                         int64_t *out, size_t *consumed);
+
 /* SignedRleV2RunIter / UnsignedRleV2RunIter (rle_v2.rs:480-514, 677-710): list the run headers
  * needed to cover `num_values`.  Writes at most `max_runs` entries, returns the count in `n_runs`. */
 int orc_oracle_rlev2_runs(const uint8_t *stream, size_t len, size_t num_values,

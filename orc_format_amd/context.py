@@ -139,6 +139,17 @@ class Context:
         check(rc, self._h)
         return out
 
+    def rlev1(self, stream, num_values, signed, entry_points=None):
+        """orcd_rlev1_decode: integer RLE version 1 (files written as ORC 0.11)."""
+        s = _host_u8(stream)
+        e, ne = _entries(entry_points)
+        out = np.empty(num_values, dtype=np.int64)
+        rc = self._lib.orcd_rlev1_decode(self._h, s.ctypes.data, s.size, num_values,
+                                         e.ctypes.data if ne else None, ne, out.ctypes.data,
+                                         N.SIGNED if signed else 0)
+        check(rc, self._h)
+        return out
+
     def rlev2_runs(self, stream, num_values, signed=False, entry_points=None):
         s = _host_u8(stream)
         e, ne = _entries(entry_points)

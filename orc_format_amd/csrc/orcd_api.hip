@@ -865,6 +865,23 @@ int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_va
     return ORCD_OK;
 }
 
+// Integer RLE version 1, device-side input and output.
+int rlev1_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
+                 const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out) {
+    if (n_entries > 0xFFFFFFFFull) return ORCD_INVALID_ARGUMENT;
+    const uint32_t n_seg = segments_for(n_entries);
+    const uint64_t *entries = n_entries ? d_entries : nullptr;
+    ScanResult sr;
+    ORCD_TRY(count_and_scan(c, n_seg, num_values, [&](const SegTable &st) {
+        return launch_rlev1_count(c->stream, d_stream, len, entries, n_seg, is_signed, st);
+    }, &sr));
+    mark(c, 1);
+    if (sr.totals.error) return (int)sr.totals.error;
+    HIP_TRY(c, launch_rlev1_emit(c->stream, d_stream, len, entries, n_seg, is_signed, sr.table, num_values, d_out));
+    mark(c, 3);
+    return ORCD_OK;
+}
+
 constexpr size_t BYTE_RLE_COMPOSE_MIN = 8 * BC_SEG;
 
 struct ByteRleTable {
@@ -1132,6 +1149,32 @@ int orcd_rlev2_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num
 
 // orcd_rlev2_decode for callers that cannot allocate: device pointers only, every table in the
 // library's static device array, limits instead of growth.
+int orcd_rlev1_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_values,
+                      const uint64_t *entry_points, size_t n_entries, int64_t *out,
+                      unsigned flags) try {
+    if (!c || (len && !stream) || (num_values && !out) || (n_entries && !entry_points))
+        return ORCD_INVALID_ARGUMENT;
+    if (num_values == 0) return ORCD_OK;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    mark(c, 0);
+    const void *d_stream, *d_entries;
+    ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t),
+                      in_dev && !(flags & ORCD_ENTRIES_HOST), &d_entries));
+    int64_t *d_out = out;
+    if (!out_dev) {
+        void *p;
+        ORCD_TRY(ensure(c, SLOT_OUT_A, num_values * sizeof(int64_t), &p));
+        d_out = (int64_t *)p;
+    }
+    ORCD_TRY(rlev1_device(c, (const uint8_t *)d_stream, len, num_values, (const uint64_t *)d_entries,
+                          n_entries, (flags & ORCD_SIGNED) ? 1 : 0, d_out));
+    if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, num_values * sizeof(int64_t)));
+    return ORCD_OK;
+} ORCD_CATCH
+
 int orcd_rlev2_decode_noalloc(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_values,
                               const uint64_t *entry_points, size_t n_entries, int64_t *out,
                               unsigned flags) try {
@@ -2109,14 +2152,16 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
     case T_SHORT: case T_INT: case T_LONG: case T_DATE: {  // deserialize_int_array, deserialize.rs:48-82
         value_size = 8;
         if (ints_done) break;
-        // ColumnEncoding DIRECT is RLE v1 (Hive 0.11 files), which is not decoded here: its bytes
-        // must not be read as RLE v2
+        // ColumnEncoding DIRECT is RLE v1 (Hive 0.11 files): its bytes must not be read as RLE v2
         int enc = 0;
         ORCD_TRY(orcd_column_encoding(col, &enc, nullptr));
-        if (enc != ORCD_ENC_DIRECT_V2) return ORCD_UNSUPPORTED;
+        if (enc != ORCD_ENC_DIRECT_V2 && enc != ORCD_ENC_DIRECT) return ORCD_UNSUPPORTED;
         ORCD_TRY(dev_alloc(c, n_values * 8, &p.values));
         ORCD_TRY(cs.get(ORCD_STREAM_DATA, &sb, &sl, &ent, &n_ent, n_values != 0));
-        ORCD_TRY(orcd_rlev2_decode(c, sb, sl, n_values, ent, n_ent, (int64_t *)p.values, ORCD_SIGNED | io));
+        if (enc == ORCD_ENC_DIRECT)  // a file written as ORC 0.11: integer RLE version 1
+            ORCD_TRY(orcd_rlev1_decode(c, sb, sl, n_values, ent, n_ent, (int64_t *)p.values, ORCD_SIGNED | io));
+        else
+            ORCD_TRY(orcd_rlev2_decode(c, sb, sl, n_values, ent, n_ent, (int64_t *)p.values, ORCD_SIGNED | io));
         break;
     }
     case T_BOOLEAN: {  // deserialize_bool_array, deserialize.rs:84-104

@@ -171,6 +171,12 @@ struct Rlev2Table {
     uint64_t num_values;
     int is_signed;
 };
+// Integer RLE version 1 (rlev2.hip, last section): values per segment into `t` (then the segment
+// scan), and -- the same walk again -- the values themselves at the segments' offsets.
+hipError_t launch_rlev1_count(hipStream_t st, const uint8_t *stream, uint64_t len, const uint64_t *entries,
+                              uint32_t n_seg, int is_signed, const SegTable &t);
+hipError_t launch_rlev1_emit(hipStream_t st, const uint8_t *stream, uint64_t len, const uint64_t *entries,
+                             uint32_t n_seg, int is_signed, const SegTable &t, uint64_t num_values, int64_t *out);
 // Speculative entry points every `spacing` bytes for an irregular stream without any (see
 // rlev2_resync_kernel): entries[0 .. n_entries), to be verified by the counting pass.
 hipError_t launch_rlev2_resync(hipStream_t st, const uint8_t *stream, uint64_t len, int is_signed,

@@ -2465,4 +2465,122 @@ hipError_t launch_rlev2_offsets(hipStream_t st, const Rlev2Table &t, const uint6
     return launch_values_mode<MODE_OFFSETS>(st, t, offsets, const_cast<uint64_t *>(group_prefix), nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Integer RLE version 1: the DATA and LENGTH streams of files written as ORC 0.11 (ColumnEncoding
+// DIRECT / DICTIONARY).  Not in the reference (README.md:23-25 lists it as missing); the layout is
+// the ORC v1 specification's: a control byte 0..127 starts a run of control + 3 values -- a signed
+// delta byte and the base as a varint, value i = base + i * delta -- and a control byte 128..255
+// starts 256 - control literal values, a varint each (zigzag for signed streams).
+//
+// Such files are rare and old; the decoder is plain.  One lane walks a segment (the groups
+// between two entry points) twice: once to count its values, then -- after the same prefix sums
+// the other decoders use -- to write them where they belong.  Literal varints have no fixed size,
+// so there is nothing to expand in parallel inside a group; the parallelism is the segments.
+// ---------------------------------------------------------------------------------------------
+
+// LEB128 at `pos` (pos < len), at most 10 bytes (rle_v2.rs:71-89), all inside the stream.
+__device__ __forceinline__ bool v1_varint(const uint8_t *s, uint64_t len, uint64_t pos, uint64_t &value,
+                                          uint32_t &used) {
+    const Window16 w = load_window(s, len, pos);
+    uint64_t v = 0;
+    for (uint32_t j = 0; j < 10; j++) {
+        if (pos + j >= len) return false;
+        const uint32_t b = w.byte(j);
+        v |= (uint64_t)(b & 0x7F) << (7 * j);
+        if ((b & 0x80) == 0) {
+            value = v;
+            used = j + 1;
+            return true;
+        }
+    }
+    return false;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(SEG_BLOCK) void rlev1_walk_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries, uint32_t n_seg,
+    int is_signed, SegTable t, uint64_t num_values, int64_t *__restrict__ out) {
+    const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
+    const bool valid = seg < n_seg;
+    uint64_t pos = (valid && entries && seg > 0) ? entries[seg] : 0;
+    uint64_t end = (valid && entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
+    const bool last_seg = seg + 1 == n_seg;
+    uint32_t n_groups = 0, last_count = 0, status = SEG_OK;
+    uint64_t n_vals = 0;
+    uint64_t out_off = 0;
+    if (pos > len) pos = len;
+    if (end > len || end < pos) status = SEG_MISALIGNED;
+    if (EMIT) {
+        if (!valid) return;
+        out_off = seg_global_offset(t, seg).val_off;
+        if (out_off >= num_values) return;  // nothing of this segment is wanted
+    }
+    if (valid && status == SEG_OK) {
+        while (pos < end) {
+            const uint32_t control = s[pos];
+            if (control < 128) {  // a run: delta byte, base varint
+                const uint32_t count = control + 3;
+                uint64_t base = 0;
+                uint32_t used = 0;
+                if (pos + 2 >= len || !v1_varint(s, len, pos + 2, base, used)) {
+                    status = pos + 2 >= len ? SEG_TRUNCATED : SEG_BAD_RUN;
+                    break;
+                }
+                if (EMIT) {
+                    const uint64_t delta = (uint64_t)(int64_t)(int8_t)s[pos + 1];
+                    if (is_signed) base = zigzag(base);
+                    for (uint32_t i = 0; i < count; i++) {
+                        const uint64_t at = out_off + n_vals + i;
+                        if (at < num_values) out[at] = (int64_t)(base + (uint64_t)i * delta);
+                    }
+                }
+                pos += 2 + used;
+                n_vals += count;
+                last_count = count;
+            } else {  // literals: a varint each
+                const uint32_t count = 256 - control;
+                uint64_t p = pos + 1;
+                bool ok = true;
+                for (uint32_t i = 0; i < count; i++) {
+                    uint64_t v = 0;
+                    uint32_t used = 0;
+                    if (p >= len || !v1_varint(s, len, p, v, used)) {
+                        status = p >= len ? SEG_TRUNCATED : SEG_BAD_RUN;
+                        ok = false;
+                        break;
+                    }
+                    if (EMIT) {
+                        const uint64_t at = out_off + n_vals + i;
+                        if (at < num_values) out[at] = (int64_t)(is_signed ? zigzag(v) : v);
+                    }
+                    p += used;
+                }
+                if (!ok) break;
+                pos = p;
+                n_vals += count;
+                last_count = count;
+            }
+            n_groups++;
+            if (EMIT && out_off + n_vals >= num_values) break;  // the rest is not wanted
+        }
+    }
+    if (EMIT) return;
+    if (status == SEG_OK && pos != end && !last_seg) status = SEG_MISALIGNED;
+    seg_publish(t, seg, n_seg, n_groups, last_count, status, n_vals);
+}
+
+hipError_t launch_rlev1_count(hipStream_t st, const uint8_t *stream, uint64_t len, const uint64_t *entries,
+                              uint32_t n_seg, int is_signed, const SegTable &t) {
+    const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
+    rlev1_walk_kernel<false><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, n_seg, is_signed, t, 0, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_rlev1_emit(hipStream_t st, const uint8_t *stream, uint64_t len, const uint64_t *entries,
+                             uint32_t n_seg, int is_signed, const SegTable &t, uint64_t num_values, int64_t *out) {
+    const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
+    rlev1_walk_kernel<true><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, n_seg, is_signed, t, num_values, out);
+    return hipGetLastError();
+}
+
 }  // namespace orcd

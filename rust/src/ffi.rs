@@ -143,6 +143,9 @@ extern "C" {
     pub fn orcd_rlev2_decode(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_values: usize,
                              entry_points: *const u64, n_entries: usize, out: *mut i64,
                              flags: c_uint) -> c_int;
+    pub fn orcd_rlev1_decode(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_values: usize,
+                             entry_points: *const u64, n_entries: usize, out: *mut i64,
+                             flags: c_uint) -> c_int;
     pub fn orcd_rlev2_decode_noalloc(ctx: *mut orcd_ctx, stream: *const u8, len: usize,
                                      num_values: usize, entry_points: *const u64, n_entries: usize,
                                      out: *mut i64, flags: c_uint) -> c_int;

@@ -45,6 +45,16 @@ class Oracle:
                                            C.byref(consumed))
         return rc, out, consumed.value
 
+    def rlev1(self, stream, n, signed):
+        s = _u8(stream)
+        out = np.empty(n, dtype=np.int64)
+        consumed = C.c_size_t(0)
+        self.lib.orc_oracle_rlev1_i64.argtypes = self.lib.orc_oracle_rlev2_i64.argtypes
+        self.lib.orc_oracle_rlev1_i64.restype = C.c_int
+        rc = self.lib.orc_oracle_rlev1_i64(s.ctypes.data, s.size, n, int(signed), out.ctypes.data,
+                                           C.byref(consumed))
+        return rc, out, consumed.value
+
     def runs(self, stream, n):
         s = _u8(stream)
         cap = max(16, min(n, s.size))  # a run takes at least two stream bytes

@@ -100,6 +100,49 @@ def patched_base(base, values, width, patches, patch_width, gap_width):
             pack_bits(np.asarray(entries, dtype=np.uint64), cfb))
 
 
+def rlev1_run(base, delta, count, signed):
+    """Integer RLE v1 run: count (3..130) values base, base + delta, ... (delta -128..127)."""
+    assert 3 <= count <= 130 and -128 <= delta <= 127
+    return bytes([count - 3, delta & 0xFF]) + (svarint(base) if signed else varint(base))
+
+
+def rlev1_literals(values, signed):
+    """Integer RLE v1 literal group of 1..128 values."""
+    assert 1 <= len(values) <= 128
+    return bytes([256 - len(values)]) + b"".join(svarint(v) if signed else varint(v) for v in values)
+
+
+def rlev1(values, signed):
+    """Integer RLE v1 encoding of `values` the way the ORC writers do it: runs of at least three
+    values with a constant delta in -128..127, everything else as literal groups.  Returns the
+    bytes and the start offset of every run / literal group."""
+    v = [int(x) for x in values]
+    out, starts, lit = bytearray(), [], []
+
+    def flush():
+        while lit:
+            starts.append(len(out))
+            out.extend(rlev1_literals(lit[:128], signed))
+            del lit[:128]
+    i, n = 0, len(v)
+    while i < n:
+        j = i + 1
+        if j < n and -128 <= v[j] - v[i] <= 127:
+            d = v[j] - v[i]
+            while j + 1 < n and v[j + 1] - v[j] == d and j + 1 - i < 130:
+                j += 1
+        if j - i + 1 >= 3 and j < n and -128 <= v[i + 1] - v[i] <= 127:
+            flush()
+            starts.append(len(out))
+            out.extend(rlev1_run(v[i], v[i + 1] - v[i], j - i + 1, signed))
+            i = j + 1
+        else:
+            lit.append(v[i])
+            i += 1
+    flush()
+    return bytes(out), starts
+
+
 def byte_rle(data, rng=None, max_literal=128):
     """Byte-RLE encoding of `data` (bytes): runs of 3..130 equal bytes, literals of 1..128."""
     data = bytes(data)

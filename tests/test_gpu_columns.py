@@ -515,15 +515,14 @@ def _pb_msg(field, payload):
     return _pb_varint((field << 3) | 2) + _pb_varint(len(payload)) + payload
 
 
-def test_rle_v1_integer_column_is_unsupported(tmp_path):
+def test_rle_v1_integer_column_of_a_hand_built_file(tmp_path):
     """A file whose footer says ColumnEncoding DIRECT (RLE v1, Hive 0.11) for an integer column:
-    its DATA bytes are not RLE v2 and must not be decoded as such.  (The crate's harness does not
-    look at the encoding of integer columns either, tests/it/deserialize.rs:48-82; what it would
-    return here is unpinned.)  The file is built by hand: no writer at hand emits RLE v1."""
+    its DATA bytes are RLE v1 and are decoded as such, never as RLE v2.  (The crate's harness does
+    not look at the encoding of integer columns, tests/it/deserialize.rs:48-82, and has no RLE v1:
+    what it would return here is unpinned.)  The file is built by hand."""
     import rle_encode as enc
     from orc_format_amd import default_context, read
-    from orc_format_amd.error import OrcError
-    data = enc.direct(np.arange(5, dtype=np.int64), 8, True)
+    data, _ = enc.rlev1(np.arange(5, dtype=np.int64), True)
     stripe_footer = (_pb_msg(1, _pb_u(1, 1) + _pb_u(2, 1) + _pb_u(3, len(data))) +
                      _pb_msg(2, _pb_u(1, 0)) + _pb_msg(2, _pb_u(1, 0)))     # both columns DIRECT
     footer = (_pb_msg(3, _pb_u(1, 3) + _pb_u(2, 0) + _pb_u(3, len(data)) + _pb_u(4, len(stripe_footer)) + _pb_u(5, 5)) +
@@ -536,7 +535,5 @@ def test_rle_v1_integer_column_is_unsupported(tmp_path):
     md = read.read_metadata(path)
     ft = read.read_stripe_footer(md, 0)
     ctx = default_context()
-    for call in (lambda: ctx.decode_column(md, 0, ft, 1), lambda: ctx.decode_stripe(md, 0, ft, [1])):
-        with pytest.raises(OrcError) as e:
-            call()
-        assert e.value.code == 100
+    assert ctx.decode_column(md, 0, ft, 1)["values"].tolist() == [0, 1, 2, 3, 4]
+    assert ctx.decode_stripe(md, 0, ft, [1])[0]["values"].tolist() == [0, 1, 2, 3, 4]

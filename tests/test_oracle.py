@@ -230,3 +230,66 @@ def test_byte_rle_writer_roundtrip(oracle):
     stream = enc.byte_rle(data)
     rc, out = oracle.byte_rle(stream, len(data))
     assert rc == 0 and out.tobytes() == bytes(data)
+
+
+def test_rlev1_specification_examples(oracle):
+    """Integer RLE version 1, the examples of the ORC v1 specification (the reference has no
+    RLE v1: README.md:23-25): a hundred sevens, 100 down to 1, and five literals."""
+    rc, out, used = oracle.rlev1(bytes([0x61, 0x00, 0x07]), 100, False)
+    assert rc == 0 and used == 3 and out.tolist() == [7] * 100
+    rc, out, used = oracle.rlev1(bytes([0x61, 0xFF, 0x64]), 100, False)
+    assert rc == 0 and out.tolist() == list(range(100, 0, -1))
+    rc, out, used = oracle.rlev1(bytes([0xFB, 0x02, 0x03, 0x06, 0x07, 0x0B]), 5, False)
+    assert rc == 0 and used == 6 and out.tolist() == [2, 3, 6, 7, 11]
+    # signed streams zigzag their varints; fewer values than the group holds; a cut stream
+    rc, out, _ = oracle.rlev1(bytes([0xFE, 0x01, 0x04]), 2, True)
+    assert rc == 0 and out.tolist() == [-1, 2]
+    rc, out, _ = oracle.rlev1(bytes([0x61, 0x00, 0x07]), 10, False)
+    assert rc == 0 and out.tolist() == [7] * 10
+    assert oracle.rlev1(bytes([0x61, 0x00]), 3, False)[0] == 1
+    assert oracle.rlev1(bytes([0xFB, 0x02, 0x03]), 5, False)[0] == 1
+    assert oracle.rlev1(bytes([0x61, 0x00, 0x07]), 101, False)[0] == 1
+
+
+def test_rlev1_encoder_round_trip(oracle):
+    import rle_encode as enc
+    rng = np.random.default_rng(4)
+    for signed in (False, True):
+        for case in range(30):
+            n = int(rng.integers(1, 3000))
+            kind = case % 3
+            if kind == 0:
+                v = rng.integers(-2**40 if signed else 0, 2**40, size=n)
+            elif kind == 1:
+                v = np.cumsum(rng.integers(-3 if signed else 0, 4, size=n)) + (0 if signed else 10)
+                v = np.abs(v) if not signed else v
+            else:
+                v = np.repeat(rng.integers(0, 50, size=n // 7 + 1), 7)[:n]
+            stream, starts = enc.rlev1(v, signed)
+            rc, out, used = oracle.rlev1(stream, len(v), signed)
+            assert rc == 0 and used == len(stream) and (out == np.asarray(v, dtype=np.int64)).all()
+
+
+def test_rlev1_against_files_written_as_version_0_11(tmp_path, oracle):
+    """Columns of a file the ORC C++ writer wrote with file version 0.11 (ColumnEncoding DIRECT,
+    RLE v1): the oracle's values are what pyarrow reads."""
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    import orc_pyparse as op
+    rng = np.random.default_rng(6)
+    rows = 20_000
+    cols = {"a": np.cumsum(rng.integers(-5, 9, size=rows)), "b": rng.integers(-2**45, 2**45, size=rows),
+            "c": np.repeat(rng.integers(0, 9, size=rows // 10), 10)}
+    path = str(tmp_path / "v011.orc")
+    orc.write_table(pa.table({k: pa.array(v) for k, v in cols.items()}), path, compression="uncompressed",
+                    file_version="0.11")
+    f = op.OrcFile(path)
+    for ci, name in enumerate(cols, start=1):
+        got = []
+        for si in range(len(f.stripes)):
+            data = f.stream(si, ci, op.DATA)
+            n = f.stripes[si].number_of_rows
+            rc, out, _ = oracle.rlev1(data, n, True)
+            assert rc == 0
+            got.append(out)
+        assert (np.concatenate(got) == cols[name]).all(), name
