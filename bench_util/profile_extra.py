@@ -1,7 +1,7 @@
 """The kernels that no bench.py workload exercises, one case each, for rocprofv3 (kernel trace and
 FETCH_SIZE / WRITE_SIZE passes): a few iterations of one large call, checked once.
 
-    python bench_util/profile_extra.py patched_base | dictionary | byte_rle | scatter
+    python bench_util/profile_extra.py patched_base | dictionary | byte_rle | scatter | rlev1
 """
 import os
 import sys
@@ -123,5 +123,34 @@ def scatter(ctx):
           (rows, n_values, dt * 1e3, rows * 8 / dt / 1e9), flush=True)
 
 
+def rlev1(ctx):
+    """10^8 values of integer RLE version 1 (a file written as ORC 0.11): 64 distinct row groups of
+    10 000 values -- slowly varying values, which the writers turn into a mix of short runs and
+    literal groups -- repeated, an entry point per row group."""
+    import rle_encode as enc
+    rng = np.random.default_rng(3)
+    groups, vals = [], []
+    for _ in range(64):
+        v = np.cumsum(rng.integers(-2, 3, size=10_000)) + int(rng.integers(-10**6, 10**6))
+        b, _starts = enc.rlev1(v, True)
+        groups.append(b)
+        vals.append(v)
+    reps = 10**8 // (64 * 10_000)
+    stream = torch.from_numpy(np.frombuffer(b"".join(groups), dtype=np.uint8).copy()).cuda().repeat(reps)
+    expect = torch.from_numpy(np.concatenate(vals)).cuda().repeat(reps)
+    starts = np.cumsum([0] + [len(b) for b in groups] * reps)[:-1]
+    entries = torch.from_numpy(starts.astype(np.int64)).cuda()
+    n = expect.numel()
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    lib = N.lib()
+    dt = timed(ctx, lambda: check(lib.orcd_rlev1_decode(
+        ctx.handle, stream.data_ptr(), stream.numel(), n, entries.data_ptr(), entries.numel(), out.data_ptr(),
+        N.SIGNED | N.IN_DEVICE | N.OUT_DEVICE), ctx.handle))
+    assert torch.equal(out, expect)
+    print("rlev1: %d values, %d stream bytes, %d entry points, %.3f ms, %.0f GB/s decoded" %
+          (n, stream.numel(), entries.numel(), dt * 1e3, n * 8 / dt / 1e9), flush=True)
+
+
 if __name__ == "__main__":
-    {"patched_base": patched_base, "dictionary": dictionary, "byte_rle": byte_rle, "scatter": scatter}[sys.argv[1]](Context(0))
+    {"patched_base": patched_base, "dictionary": dictionary, "byte_rle": byte_rle, "scatter": scatter,
+     "rlev1": rlev1}[sys.argv[1]](Context(0))

@@ -43,7 +43,7 @@ enum {
     ORCD_DECODE_FLOAT = 5,
     ORCD_DECOMPRESSION = 6,
     ORCD_INVALID_PROTO = 7,
-    ORCD_UNSUPPORTED = 100, /* the crate panics with todo!() here (e.g. LZO-compressed files, RLE v1) */
+    ORCD_UNSUPPORTED = 100, /* the crate panics with todo!() here (e.g. LZO-compressed files, timestamp columns) */
     ORCD_HIP_ERROR = 101,
     ORCD_INVALID_ARGUMENT = 102,
     ORCD_NO_MEMORY = 103 /* host memory ran out inside the library */
@@ -57,7 +57,8 @@ enum {
     ORCD_CHECK_UTF8 = 8u,  /* strings: validate each value (tests/it/deserialize.rs:116-118) */
     ORCD_SCATTER_CARRY = 16u, /* orcd_scatter_valid: null rows repeat the next value (offsets) */
     ORCD_ROW_ALIGNED = 32u, /* orcd_decode_column: one slot per row instead of per non-null row */
-    ORCD_ENTRIES_HOST = 64u /* with ORCD_IN_DEVICE: the entry points are host memory all the same */
+    ORCD_ENTRIES_HOST = 64u, /* with ORCD_IN_DEVICE: the entry points are host memory all the same */
+    ORCD_LENGTH_RLE_V1 = 128u /* orcd_string_direct_decode: the LENGTH stream is integer RLE version 1 (ORC 0.11 files) */
 };
 
 /* ---- stream kinds (src/proto.rs:127-136) and column encodings (src/proto.rs:149-154) -------- */

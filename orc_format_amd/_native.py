@@ -13,7 +13,7 @@ OK, OUT_OF_SPEC, INVALID_UTF8, INVALID_COLUMN, INVALID_KIND, DECODE_FLOAT, DECOM
     INVALID_PROTO = range(8)
 UNSUPPORTED, HIP_ERROR, INVALID_ARGUMENT, NO_MEMORY = 100, 101, 102, 103
 
-SIGNED, IN_DEVICE, OUT_DEVICE, CHECK_UTF8, SCATTER_CARRY, ROW_ALIGNED, ENTRIES_HOST = 1, 2, 4, 8, 16, 32, 64
+SIGNED, IN_DEVICE, OUT_DEVICE, CHECK_UTF8, SCATTER_CARRY, ROW_ALIGNED, ENTRIES_HOST, LENGTH_RLE_V1 = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class OrcdRun(C.Structure):

@@ -1645,17 +1645,25 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
         ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, length_entry_points, n_length_entries * sizeof(uint64_t),
                           in_dev && !(flags & ORCD_ENTRIES_HOST), &d_entries));
         const uint8_t *ls = (const uint8_t *)d_len_stream;
+        const bool v1 = (flags & ORCD_LENGTH_RLE_V1) != 0;
         Rlev2Table t;
+        void *gsums = nullptr, *sums, *flag;
+        ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
+        uint32_t bad = 0;
+        if (v1) {
+            // a file written as ORC 0.11: the lengths are decoded as they are and scanned in place
+            ORCD_TRY(rlev1_device(c, ls, length_len, num_values, (const uint64_t *)d_entries, n_length_entries, 0,
+                                  d_offsets));
+            ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(num_values) * sizeof(uint64_t), &sums));
+        } else {
         ORCD_TRY(rlev2_table(c, ls, length_len, num_values, (const uint64_t *)d_entries,
                              n_length_entries, 0, &t));
         // Offsets are the exclusive prefix sums of the lengths (variable_length.rs:15-23: each
         // next(len) continues where the last one ended).  The lengths themselves are never
         // stored: one pass over the LENGTH stream reduces every group of runs to its sum, the
         // few group sums are scanned, and a second pass expands the runs straight into offsets.
-        void *gsums, *sums, *flag;
         ORCD_TRY(ensure(c, SLOT_TMP, ((size_t)t.n_groups + 1) * sizeof(uint64_t), &gsums));
         ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(std::max<uint64_t>(num_values, t.n_groups)) * sizeof(uint64_t), &sums));
-        ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
         HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
         HIP_TRY(c, launch_rlev2_group_sums(c->stream, t, (uint64_t *)gsums, (uint32_t *)flag));
         HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)gsums, t.n_groups, (uint64_t *)sums,
@@ -1664,12 +1672,13 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
                                   hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        uint32_t bad = *(uint32_t *)(c->h_scalars + 1);
+        bad = *(uint32_t *)(c->h_scalars + 1);
         total = c->h_scalars[0];
-        if (bad & 4u) {
+        }
+        if (v1 || (bad & 4u)) {
             // PatchedBase runs in the LENGTH stream: their patches are applied after the fact,
             // so the lengths are materialised and scanned in place
-            HIP_TRY(c, launch_rlev2_values(c->stream, t, d_offsets));
+            if (!v1) HIP_TRY(c, launch_rlev2_values(c->stream, t, d_offsets));
             HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
             HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)d_offsets, num_values,
                                                  (uint64_t *)sums, data_len, (uint32_t *)flag));
@@ -2195,13 +2204,17 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
         const uint64_t *lent;
         size_t n_lent;
         ORCD_TRY(dev_alloc(c, (n_values + 1) * 8, &p.offsets));
-        if (enc == ORCD_ENC_DIRECT_V2) {  // deserialize_str_array_direct, deserialize.rs:187-201
+        // (ColumnEncoding DIRECT / DICTIONARY: a file written as ORC 0.11, whose integer streams --
+        // LENGTH, the dictionary indices -- are RLE version 1)
+        const bool v1 = enc == ORCD_ENC_DIRECT || enc == ORCD_ENC_DICTIONARY;
+        const unsigned len_v1 = v1 ? (unsigned)ORCD_LENGTH_RLE_V1 : 0u;
+        if (enc == ORCD_ENC_DIRECT_V2 || enc == ORCD_ENC_DIRECT) {  // deserialize_str_array_direct, deserialize.rs:187-201
             ORCD_TRY(cs.get(ORCD_STREAM_LENGTH, &lb, &ll, &lent, &n_lent, n_values != 0));
             ORCD_TRY(cs.get(ORCD_STREAM_DATA, &sb, &sl, &ent, &n_ent, false));
             ORCD_TRY(dev_alloc(c, sl, &p.bytes));
             ORCD_TRY(orcd_string_direct_decode(c, lb, ll, lent, n_lent, sb, sl, n_values,
-                                               (int64_t *)p.offsets, (uint8_t *)p.bytes, io | utf8));
-        } else if (enc == ORCD_ENC_DICTIONARY_V2) {  // deserialize_str_dict_array, deserialize.rs:142-185
+                                               (int64_t *)p.offsets, (uint8_t *)p.bytes, io | utf8 | len_v1));
+        } else if (enc == ORCD_ENC_DICTIONARY_V2 || enc == ORCD_ENC_DICTIONARY) {  // deserialize_str_dict_array, deserialize.rs:142-185
             ORCD_TRY(cs.get(ORCD_STREAM_LENGTH, &lb, &ll, &lent, &n_lent, dict_size != 0));
             ORCD_TRY(cs.get(ORCD_STREAM_DICTIONARY_DATA, &sb, &sl, &ent, &n_ent, false));
             // the dictionary: offsets[dict_size + 1] and its bytes, on the device
@@ -2209,14 +2222,15 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
             ORCD_TRY(dev_alloc(c, sl, &p.tmp2));
             // (the LENGTH stream of a dictionary has no ROW_INDEX positions of its own)
             ORCD_TRY(orcd_string_direct_decode(c, lb, ll, nullptr, 0, sb, sl, dict_size, (int64_t *)p.tmp,
-                                               (uint8_t *)p.tmp2, io | utf8));
+                                               (uint8_t *)p.tmp2, io | utf8 | len_v1));
             // the indices: one per non-null row
             void *d_idx;
             ORCD_TRY(ensure(c, SLOT_OUT_B, n_values * 8, &d_idx));
             const uint8_t *ib;
             size_t il;
             ORCD_TRY(cs.get(ORCD_STREAM_DATA, &ib, &il, &ent, &n_ent, n_values != 0));
-            ORCD_TRY(orcd_rlev2_decode(c, ib, il, n_values, ent, n_ent, (int64_t *)d_idx, io));
+            if (v1) ORCD_TRY(orcd_rlev1_decode(c, ib, il, n_values, ent, n_ent, (int64_t *)d_idx, io));
+            else ORCD_TRY(orcd_rlev2_decode(c, ib, il, n_values, ent, n_ent, (int64_t *)d_idx, io));
             // how many bytes the column holds is known after the first phase: the bytes array is
             // allocated at exactly that size (a bound from the longest entry could be absurd)
             if (n_values == 0) {
@@ -2236,7 +2250,7 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
                                                     chunk_prefix, (int64_t *)p.offsets, (uint8_t *)p.bytes));
             }
         } else {
-            return ORCD_UNSUPPORTED;  // RLE v1 encodings (README.md:23-25 of the crate: not implemented there either)
+            return ORCD_UNSUPPORTED;  // an encoding the format does not define
         }
         HIP_TRY(c, hipMemcpyAsync(c->h_scalars, (int64_t *)p.offsets + n_values, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));

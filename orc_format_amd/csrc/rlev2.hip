@@ -2472,90 +2472,139 @@ hipError_t launch_rlev2_offsets(hipStream_t st, const Rlev2Table &t, const uint6
 // delta byte and the base as a varint, value i = base + i * delta -- and a control byte 128..255
 // starts 256 - control literal values, a varint each (zigzag for signed streams).
 //
-// Such files are rare and old; the decoder is plain.  One lane walks a segment (the groups
-// between two entry points) twice: once to count its values, then -- after the same prefix sums
-// the other decoders use -- to write them where they belong.  Literal varints have no fixed size,
-// so there is nothing to expand in parallel inside a group; the parallelism is the segments.
+// A wavefront walks a segment (the groups between two entry points) twice: once to count its
+// values, then -- after the same prefix sums the other decoders use -- to write them where they
+// belong.  The stream passes through LDS in tiles of V1_TILE bytes; a group is decoded only when
+// all of it lies in the tile.  Inside a literal group the wavefront looks at 64 bytes at a time,
+// a lane per byte: a byte without the continuation bit ends a varint, so one ballot gives every
+// varint's start, length and index (the number of ends in front of it), and the lane on a start
+// byte assembles and stores that value.  A step takes the bytes up to the last end it sees, or up
+// to the group's last value.
 // ---------------------------------------------------------------------------------------------
 
-// LEB128 at `pos` (pos < len), at most 10 bytes (rle_v2.rs:71-89), all inside the stream.
-__device__ __forceinline__ bool v1_varint(const uint8_t *s, uint64_t len, uint64_t pos, uint64_t &value,
-                                          uint32_t &used) {
-    const Window16 w = load_window(s, len, pos);
-    uint64_t v = 0;
-    for (uint32_t j = 0; j < 10; j++) {
-        if (pos + j >= len) return false;
-        const uint32_t b = w.byte(j);
-        v |= (uint64_t)(b & 0x7F) << (7 * j);
-        if ((b & 0x80) == 0) {
-            value = v;
-            used = j + 1;
-            return true;
-        }
-    }
-    return false;
-}
+constexpr uint32_t V1_TILE = 4096;  // bytes per wavefront in LDS (a literal group is at most 1281)
+constexpr uint32_t V1_WAVES = 4;    // wavefronts (= segments) per workgroup
 
 template <bool EMIT>
-__global__ __launch_bounds__(SEG_BLOCK) void rlev1_walk_kernel(
+__global__ __launch_bounds__(V1_WAVES * 64) void rlev1_walk_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries, uint32_t n_seg,
     int is_signed, SegTable t, uint64_t num_values, int64_t *__restrict__ out) {
-    const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
-    const bool valid = seg < n_seg;
-    uint64_t pos = (valid && entries && seg > 0) ? entries[seg] : 0;
-    uint64_t end = (valid && entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
+    __shared__ __align__(16) uint8_t tiles[V1_WAVES][V1_TILE];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t seg = blockIdx.x * V1_WAVES + wave;
+    if (seg >= n_seg) return;  // (no workgroup barrier below: a wavefront may leave alone)
+    uint8_t *tile = tiles[wave];
+    uint64_t pos = (entries && seg > 0) ? entries[seg] : 0;
+    uint64_t end = (entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
     const bool last_seg = seg + 1 == n_seg;
     uint32_t n_groups = 0, last_count = 0, status = SEG_OK;
-    uint64_t n_vals = 0;
-    uint64_t out_off = 0;
+    uint64_t n_vals = 0, out_off = 0;
     if (pos > len) pos = len;
     if (end > len || end < pos) status = SEG_MISALIGNED;
     if (EMIT) {
-        if (!valid) return;
         out_off = seg_global_offset(t, seg).val_off;
         if (out_off >= num_values) return;  // nothing of this segment is wanted
     }
-    if (valid && status == SEG_OK) {
+
+    // the tile holds the bytes at addresses [tile_at, tile_at + V1_TILE), tile_at a multiple of 16
+    const uintptr_t s_addr = (uintptr_t)s, lim_addr = s_addr + len;
+    uintptr_t tile_at = 0;
+    bool loaded = false;
+    auto fill = [&](uint64_t p) {
+        tile_at = (s_addr + p) & ~(uintptr_t)15;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t k = 0; k < V1_TILE / 1024; k++) {
+            const uintptr_t a = tile_at + (uintptr_t)(k * 64 + lane) * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a < lim_addr) v = *(const uint4 *)a;  // (the 16 bytes around the stream's ends are read whole)
+            ((uint4 *)tile)[k * 64 + lane] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        loaded = true;
+    };
+    // the n bytes at p (p < len), as far as the stream goes, are in the tile afterwards
+    auto ensure = [&](uint64_t p, uint32_t n) {
+        const uint64_t last = p + n < len ? p + n : len;
+        if (!loaded || s_addr + last > tile_at + V1_TILE) fill(p);
+    };
+    auto in_tile = [&](uint64_t p) { return p < len && s_addr + p < tile_at + V1_TILE; };
+    auto at = [&](uint64_t p) -> uint32_t { return tile[(s_addr + p) - tile_at]; };
+
+    if (status == SEG_OK) {
         while (pos < end) {
-            const uint32_t control = s[pos];
-            if (control < 128) {  // a run: delta byte, base varint
+            ensure(pos, 12);
+            const uint32_t control = (uint32_t)__builtin_amdgcn_readfirstlane((int)at(pos));
+            if (control < 128) {  // a run: delta byte, base varint (at most 10 bytes, rle_v2.rs:71-89)
                 const uint32_t count = control + 3;
-                uint64_t base = 0;
-                uint32_t used = 0;
-                if (pos + 2 >= len || !v1_varint(s, len, pos + 2, base, used)) {
-                    status = pos + 2 >= len ? SEG_TRUNCATED : SEG_BAD_RUN;
+                if (pos + 2 >= len) {
+                    status = SEG_TRUNCATED;
                     break;
                 }
+                const uint64_t delta = (uint64_t)(int64_t)(int8_t)at(pos + 1);
+                const uint64_t q = pos + 2 + lane;
+                const bool in = lane < 10 && q < len;
+                const uint32_t b = in ? at(q) : 0x80u;
+                const uint64_t ends = __ballot(in && !(b & 0x80));
+                if (!ends) {
+                    status = SEG_BAD_RUN;
+                    break;
+                }
+                const uint32_t u = (uint32_t)__builtin_ctzll(ends);
                 if (EMIT) {
-                    const uint64_t delta = (uint64_t)(int64_t)(int8_t)s[pos + 1];
+                    uint64_t base = 0;
+                    for (uint32_t j = 0; j <= u; j++) base |= (uint64_t)(readlane32(b, (int)j) & 0x7F) << (7 * j);
                     if (is_signed) base = zigzag(base);
-                    for (uint32_t i = 0; i < count; i++) {
-                        const uint64_t at = out_off + n_vals + i;
-                        if (at < num_values) out[at] = (int64_t)(base + (uint64_t)i * delta);
+                    for (uint32_t i = lane; i < count; i += 64) {
+                        const uint64_t idx = out_off + n_vals + i;
+                        if (idx < num_values) out[idx] = (int64_t)(base + (uint64_t)i * delta);
                     }
                 }
-                pos += 2 + used;
+                pos += 3 + u;
                 n_vals += count;
                 last_count = count;
             } else {  // literals: a varint each
                 const uint32_t count = 256 - control;
+                ensure(pos, 1 + 10 * count);
                 uint64_t p = pos + 1;
-                bool ok = true;
-                for (uint32_t i = 0; i < count; i++) {
-                    uint64_t v = 0;
-                    uint32_t used = 0;
-                    if (p >= len || !v1_varint(s, len, p, v, used)) {
-                        status = p >= len ? SEG_TRUNCATED : SEG_BAD_RUN;
-                        ok = false;
+                uint32_t done = 0;
+                while (done < count) {
+                    const uint64_t q = p + lane;
+                    const bool in = in_tile(q);
+                    const uint32_t b = in ? at(q) : 0x80u;
+                    const uint64_t ends = __ballot(in && !(b & 0x80));
+                    if (!ends) {  // 64 bytes and no varint ends, or the stream does
+                        status = p + 10 > len ? SEG_TRUNCATED : SEG_BAD_RUN;
                         break;
                     }
-                    if (EMIT) {
-                        const uint64_t at = out_off + n_vals + i;
-                        if (at < num_values) out[at] = (int64_t)(is_signed ? zigzag(v) : v);
+                    const uint32_t rank = (uint32_t)__popcll(ends & ((1ull << lane) - 1));  // ends in front of this byte
+                    const uint32_t seen = (uint32_t)__popcll(ends);
+                    uint32_t take, bytes;
+                    if (done + seen >= count) {  // the group's last value ends in this step
+                        take = count - done;
+                        const uint64_t hit = __ballot(((ends >> lane) & 1) && rank == take - 1);
+                        bytes = (uint32_t)__builtin_ctzll(hit) + 1;
+                    } else {
+                        take = seen;
+                        bytes = 64 - (uint32_t)__builtin_clzll(ends);
                     }
-                    p += used;
+                    const bool starts = (lane == 0 || ((ends >> (lane - 1)) & 1)) && lane < bytes;
+                    const uint32_t my_len = (uint32_t)__builtin_ctzll((ends >> lane) | (1ull << 63)) + 1;
+                    if (__ballot(starts && my_len > 10)) {
+                        status = SEG_BAD_RUN;
+                        break;
+                    }
+                    if (EMIT && starts) {
+                        uint64_t v = 0;
+                        for (uint32_t j = 0; j < my_len; j++) v |= (uint64_t)(at(q + j) & 0x7F) << (7 * j);
+                        const uint64_t idx = out_off + n_vals + done + rank;
+                        if (idx < num_values) out[idx] = (int64_t)(is_signed ? zigzag(v) : v);
+                    }
+                    p += bytes;
+                    done += take;
                 }
-                if (!ok) break;
+                if (status != SEG_OK) break;
                 pos = p;
                 n_vals += count;
                 last_count = count;
@@ -2566,20 +2615,37 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev1_walk_kernel(
     }
     if (EMIT) return;
     if (status == SEG_OK && pos != end && !last_seg) status = SEG_MISALIGNED;
-    seg_publish(t, seg, n_seg, n_groups, last_count, status, n_vals);
+    if (lane == 0) {
+        SegCount c;
+        c.n_runs = n_groups;
+        c.last_len = last_count;
+        c.status = status;
+        c.pad = 0;
+        c.n_vals = n_vals;
+        t.seg_count[seg] = c;
+    }
+}
+
+// The wavefronts' results, a lane per segment again, into the workgroup-local prefix sums.
+__global__ __launch_bounds__(SEG_BLOCK) void rlev1_publish_kernel(SegTable t, uint32_t n_seg) {
+    const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
+    SegCount c = {0, 0, SEG_OK, 0, 0};
+    if (seg < n_seg) c = t.seg_count[seg];
+    seg_publish(t, seg, n_seg, c.n_runs, c.last_len, c.status, c.n_vals);
 }
 
 hipError_t launch_rlev1_count(hipStream_t st, const uint8_t *stream, uint64_t len, const uint64_t *entries,
                               uint32_t n_seg, int is_signed, const SegTable &t) {
-    const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
-    rlev1_walk_kernel<false><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, n_seg, is_signed, t, 0, nullptr);
+    rlev1_walk_kernel<false><<<(n_seg + V1_WAVES - 1) / V1_WAVES, V1_WAVES * 64, 0, st>>>(
+        stream, len, entries, n_seg, is_signed, t, 0, nullptr);
+    rlev1_publish_kernel<<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(t, n_seg);
     return hipGetLastError();
 }
 
 hipError_t launch_rlev1_emit(hipStream_t st, const uint8_t *stream, uint64_t len, const uint64_t *entries,
                              uint32_t n_seg, int is_signed, const SegTable &t, uint64_t num_values, int64_t *out) {
-    const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
-    rlev1_walk_kernel<true><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, n_seg, is_signed, t, num_values, out);
+    rlev1_walk_kernel<true><<<(n_seg + V1_WAVES - 1) / V1_WAVES, V1_WAVES * 64, 0, st>>>(
+        stream, len, entries, n_seg, is_signed, t, num_values, out);
     return hipGetLastError();
 }
 

@@ -40,6 +40,7 @@ pub const ORCD_CHECK_UTF8: c_uint = 8;
 pub const ORCD_SCATTER_CARRY: c_uint = 16;
 pub const ORCD_ROW_ALIGNED: c_uint = 32;
 pub const ORCD_ENTRIES_HOST: c_uint = 64;
+pub const ORCD_LENGTH_RLE_V1: c_uint = 128;
 pub const ORCD_NOALLOC_MAX_VALUES: usize = 16777216;
 pub const ORCD_NOALLOC_MAX_ENTRIES: usize = 65536;
 pub const ORCD_NOALLOC_MAX_RUNS: usize = 524288;

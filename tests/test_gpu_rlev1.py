@@ -126,13 +126,45 @@ def test_columns_of_a_file_written_as_version_0_11(tmp_path):
             assert np.array_equal(cols[3]["values"], np.array(part.column("d").to_pylist()))
             first += n
     assert first == rows
-    # string columns of such files (LENGTH as RLE v1) are not decoded: unsupported, not garbage
-    from orc_format_amd.error import OrcError
-    spath = str(tmp_path / "v011s.orc")
-    orc.write_table(pa.table({"s": pa.array(["x%d" % k for k in range(1000)])}), spath,
-                    compression="uncompressed", file_version="0.11")
-    md = read.read_metadata(spath)
-    with Context(0) as ctx:
-        with pytest.raises(OrcError) as e:
-            ctx.decode_stripe(md, 0, read.read_stripe_footer(md, 0), [1])
-        assert e.value.code == 100
+
+
+def test_string_columns_of_a_file_written_as_version_0_11(tmp_path):
+    """Direct and dictionary string columns of a version-0.11 file: LENGTH and the dictionary
+    indices are RLE v1 there; with nulls, empty strings and multi-byte characters."""
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    from orc_format_amd import Context, read
+    rng = np.random.default_rng(8)
+    rows = 60_000
+    words = ["", "a", "bb", "ccc", "häuser", "日本語", "x" * 40] + ["w%d" % k for k in range(200)]
+    table = pa.table({
+        "direct": pa.array(["%x-%d" % (k, k % 7) for k in rng.integers(0, 2**50, size=rows)],
+                           mask=rng.random(rows) < 0.1),
+        "dict": pa.array([words[k] for k in rng.integers(0, len(words), size=rows)], mask=rng.random(rows) < 0.2),
+    })
+    for threshold in (0.0, 1.0):   # everything direct / dictionaries where they pay
+        path = str(tmp_path / ("v011s_%d.orc" % int(threshold)))
+        orc.write_table(table, path, compression="uncompressed", file_version="0.11", stripe_size=1 << 20,
+                        dictionary_key_size_threshold=threshold)
+        want = orc.ORCFile(path).read()
+        md = read.read_metadata(path)
+        first = 0
+        encodings = set()
+        with Context(0) as ctx:
+            for si in range(len(md.stripes)):
+                footer = read.read_stripe_footer(md, si)
+                for col in (1, 2):
+                    encodings.add(int(read.read_stripe_column(md, si, footer, col).encoding()))
+                cols = ctx.decode_stripe(md, si, footer, [1, 2])
+                n = cols[0]["validity"].size
+                part = want.slice(first, n)
+                for ci, name in enumerate(["direct", "dict"]):
+                    ref = part.column(name)
+                    assert cols[ci]["validity"].tolist() == ref.is_valid().to_pylist()
+                    raw, off = cols[ci]["bytes"].tobytes(), cols[ci]["offsets"]
+                    got = [raw[off[i]:off[i + 1]].decode() for i in range(len(off) - 1)]
+                    assert got == ref.drop_null().to_pylist(), (threshold, si, name)
+                first += n
+        assert first == rows
+        assert encodings <= {0, 1}, encodings   # DIRECT / DICTIONARY: the version-1 encodings
+    assert True
