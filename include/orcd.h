@@ -141,13 +141,31 @@ int orcd_rlev2_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t n
                       const uint64_t *entry_points, size_t n_entries, int64_t *out,
                       unsigned flags);
 
+/* Compression chunks of a zlib file inflated on the device, a wavefront per chunk: what the crate's
+ * Decompressor does one chunk at a time on the host (src/read/decompress/mod.rs:60-80: a chunk
+ * whose header says "compressed" is a raw deflate stream, handed to flate2).  chunks[k] names the
+ * deflate bytes of chunk k inside src (after its 3-byte header), the place in dst its output goes
+ * to and the room there (the file's compression block size: a chunk that decompresses to more does
+ * not inflate).  sizes[k] (host memory) receives the bytes chunk k decompressed to, or 0xFFFFFFFF;
+ * the call returns ORCD_DECOMPRESSION when any chunk does not inflate -- the same chunks as zlib
+ * refuses.  Flags: ORCD_IN_DEVICE (src), ORCD_OUT_DEVICE (dst); `chunks` and `sizes` are host
+ * memory.  The places in dst must not overlap. */
+typedef struct {
+    uint64_t src_offset;
+    uint64_t dst_offset;
+    uint32_t src_length;
+    uint32_t dst_capacity;
+} orcd_chunk;
+int orcd_inflate_chunks(orcd_ctx *ctx, const uint8_t *src, size_t src_len, const orcd_chunk *chunks,
+                        size_t n_chunks, uint8_t *dst, size_t dst_len, uint32_t *sizes, unsigned flags);
+
 /* Integer RLE version 1: the DATA / LENGTH streams of files written as ORC 0.11 (ColumnEncoding
  * DIRECT / DICTIONARY).  The crate does not decode it (README.md:23-25 lists RLE v1 as missing; its
  * harness reads every integer stream as RLE v2, tests/it/deserialize.rs:48-82); the layout is the
  * ORC v1 specification's -- runs of 3..130 values with a delta of -128..127, groups of 1..128
  * literal varints.  Same contract as orcd_rlev2_decode: `num_values` values into out[], the same
- * flags, `entry_points` at starts of runs or literal groups (a walk of one lane per segment: a
- * stream without entry points is walked by a single lane). */
+ * flags, `entry_points` at starts of runs or literal groups (a wavefront walks a segment: a stream
+ * without entry points is walked by a single wavefront). */
 int orcd_rlev1_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_values,
                       const uint64_t *entry_points, size_t n_entries, int64_t *out,
                       unsigned flags);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "orcd_ctx_last_path": (C.c_int, [P]),
     "orcd_rlev2_decode": (C.c_int, [P, P, SZ, SZ, U64P, SZ, P, C.c_uint]),
     "orcd_rlev1_decode": (C.c_int, [P, P, SZ, SZ, U64P, SZ, P, C.c_uint]),
+    "orcd_inflate_chunks": (C.c_int, [P, P, SZ, P, SZ, P, SZ, P, C.c_uint]),
     "orcd_rlev2_decode_noalloc": (C.c_int, [P, P, SZ, SZ, U64P, SZ, P, C.c_uint]),
     "orcd_rlev2_decode_batch": (C.c_int, [P, P, SZ, C.POINTER(Rlev2Slice), SZ, P, C.POINTER(SZ), C.c_uint]),
     "orcd_boolean_decode_batch": (C.c_int, [P, P, SZ, C.POINTER(Rlev2Slice), SZ, P, C.POINTER(C.c_uint64),

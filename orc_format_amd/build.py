@@ -7,8 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liborcd.so")
-SOURCES = ["rlev2.hip", "byte_rle.hip", "strings.hip", "scatter.hip", "orcd_api.hip", "orcd_host.cpp"]
-HEADERS = ["orcd_internal.h", "seg_scan.h", os.path.join("..", "..", "include", "orcd.h")]
+SOURCES = ["rlev2.hip", "byte_rle.hip", "strings.hip", "scatter.hip", "inflate.hip", "orcd_api.hip", "orcd_host.cpp"]
+HEADERS = ["orcd_internal.h", "orcd_column_internal.h", "seg_scan.h", os.path.join("..", "..", "include", "orcd.h")]
 
 
 def _hipcc():

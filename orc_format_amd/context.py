@@ -150,6 +150,21 @@ class Context:
         check(rc, self._h)
         return out
 
+    def inflate_chunks(self, src, chunks, dst_len):
+        """orcd_inflate_chunks: `chunks` is a sequence of (src_offset, src_length, dst_offset,
+        dst_capacity); returns (dst bytes as a uint8 array of dst_len, sizes)."""
+        s = _host_u8(src)
+        table = np.zeros(len(chunks), dtype=[("src_offset", "<u8"), ("dst_offset", "<u8"),
+                                             ("src_length", "<u4"), ("dst_capacity", "<u4")])
+        for k, (so, sl, do, dc) in enumerate(chunks):
+            table[k] = (so, do, sl, dc)
+        out = np.zeros(dst_len, dtype=np.uint8)
+        sizes = np.zeros(len(chunks), dtype=np.uint32)
+        rc = self._lib.orcd_inflate_chunks(self._h, s.ctypes.data, s.size, table.ctypes.data, len(chunks),
+                                           out.ctypes.data, dst_len, sizes.ctypes.data, 0)
+        check(rc, self._h)
+        return out, sizes
+
     def rlev2_runs(self, stream, num_values, signed=False, entry_points=None):
         s = _host_u8(stream)
         e, ne = _entries(entry_points)

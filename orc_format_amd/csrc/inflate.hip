@@ -1,0 +1,422 @@
+// Inflating the compression chunks of a zlib-compressed ORC file on the device.
+//
+// Every stream of such a file is a chain of chunks (src/read/decompress/mod.rs:9-17: a 3-byte
+// header, then that many bytes), each a raw deflate stream of its own (mod.rs:60-80 hands them to
+// flate2 one at a time) that decompresses to at most the file's compression block size.  A stripe
+// holds hundreds to thousands of them, independent of each other: one wavefront inflates one chunk.
+//
+// Inside a chunk deflate is serial -- a symbol's position in the bit stream is known only when the
+// symbol before it has been decoded -- so the wavefront decodes symbols as one (every lane holds the
+// same bit buffer) and uses its lanes where there is something to share out: building the Huffman
+// tables of a block, copying a match, writing finished output to memory.  What the wavefront keeps
+// in LDS: the last 32 KiB of output (all a match may refer to), a tile of the compressed bytes, and
+// per code a table that resolves codes of up to 10 bits in one look (longer ones, which are rare
+// by construction, take the canonical walk over the per-length counts).
+//
+// The checks are those of zlib's inflate, so that the same chunks are accepted and refused as by
+// the host path: block type 3, stored lengths that do not match, more than 286 / 30 symbols, code
+// length sets that are over-subscribed or incomplete (but for a single one-bit code), a repeat
+// with nothing to repeat or past the end, no end-of-block code, the symbols 286, 287, 30 and 31,
+// a distance beyond the output so far, input that ends before the last block does, and output
+// beyond the room given.
+#include "orcd_internal.h"
+
+namespace orcd {
+
+namespace {
+
+constexpr uint32_t INF_WIN = 32768;   // bytes of output kept (the most a distance can be)
+constexpr uint32_t INF_IN = 1024;     // compressed bytes held at a time
+constexpr uint32_t INF_FAST = 10;     // codes up to this many bits resolve in one look
+constexpr uint32_t INF_FLUSH = 4096;  // finished output goes to memory in pieces of at least this
+
+struct HuffTable {
+    uint16_t fast[1u << INF_FAST];  // by the next INF_FAST bits: symbol << 4 | length, 0: longer or no code
+    uint16_t count[16];             // codes of each length
+    uint16_t first_code[16];        // scratch of the build: the first code of each length
+    uint16_t first_slot[16];        // ... and where its symbols start in `sorted`
+    uint16_t sorted[288];           // symbols by (length, symbol)
+};
+
+struct Lds {
+    uint8_t window[INF_WIN];
+    uint8_t in[INF_IN];
+    HuffTable lit, dist;
+    uint8_t lens[352];  // code-length code lengths at 0, the block's two length lists from 32 on
+};
+
+// Length symbol 257 + s: 3..10 one by one, then four symbols to each number of extra bits, 258 last.
+__device__ __forceinline__ void length_code(uint32_t s, uint32_t &base, uint32_t &extra) {
+    if (s < 8) {
+        base = 3 + s;
+        extra = 0;
+    } else if (s == 28) {
+        base = 258;
+        extra = 0;
+    } else {
+        extra = (s >> 2) - 1;
+        base = 3 + ((4 + (s & 3)) << extra);
+    }
+}
+// Distance symbol d: 1..4 one by one, then two symbols to each number of extra bits.
+__device__ __forceinline__ void distance_code(uint32_t d, uint32_t &base, uint32_t &extra) {
+    if (d < 4) {
+        base = 1 + d;
+        extra = 0;
+    } else {
+        extra = (d >> 1) - 1;
+        base = 1 + ((2 + (d & 1)) << extra);
+    }
+}
+__constant__ uint8_t CLEN_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// Builds the decoding tables of one code from lens[0, n_sym) (in LDS).  `one_bit_ok`: an
+// incomplete set is accepted when its longest code has one bit (zlib's rule for the literal/length
+// and distance codes; never for the code-length code).  False: the set is not a prefix code.
+__device__ bool build_table(HuffTable &t, const uint8_t *lens, uint32_t n_sym, bool one_bit_ok, uint32_t lane) {
+    for (uint32_t i = lane; i < (1u << INF_FAST) / 2; i += 64) ((uint32_t *)t.fast)[i] = 0;
+    if (lane < 16) {  // lane l counts the codes of l bits
+        uint32_t n = 0;
+        for (uint32_t s = 0; s < n_sym; s++) n += (lens[s] == lane);
+        t.count[lane] = (uint16_t)(lane ? n : 0);
+    }
+    lds_fence();
+    uint32_t longest = 0, code = 0, slot = 0;
+    int32_t left = 1;
+    bool over = false;
+    for (uint32_t l = 1; l <= 15; l++) {
+        const uint32_t n = uni(t.count[l]);
+        if (n) longest = l;
+        left = (left << 1) - (int32_t)n;
+        if (left < 0) over = true;
+        if (left < 0) left = 0;  // (keeps the shifts small; the set is refused below)
+        if (lane == 0) {
+            t.first_code[l] = (uint16_t)code;
+            t.first_slot[l] = (uint16_t)slot;
+        }
+        code = (code + n) << 1;
+        slot += n;
+    }
+    lds_fence();
+    if (over) return false;
+    if (longest == 0) return true;  // no code at all: every look-up fails
+    if (left > 0 && !(one_bit_ok && longest == 1)) return false;
+    if (lane >= 1 && lane < 16 && t.count[lane]) {  // lane l hands out the codes of l bits, in symbol order
+        uint32_t c = t.first_code[lane], at = t.first_slot[lane];
+        for (uint32_t s = 0; s < n_sym; s++) {
+            if (lens[s] != lane) continue;
+            t.sorted[at++] = (uint16_t)s;
+            if (lane <= INF_FAST) {  // the code arrives lowest bit first: every index that ends in it, reversed
+                const uint32_t rev = __brev(c) >> (32 - lane);
+                for (uint32_t i = rev; i < (1u << INF_FAST); i += 1u << lane) t.fast[i] = (uint16_t)((s << 4) | lane);
+            }
+            c++;
+        }
+    }
+    lds_fence();
+    return true;
+}
+
+// The symbol the low bits of `bits` start with; `used`: its length, 0 when they start no code.
+__device__ __forceinline__ uint32_t decode_symbol(const HuffTable &t, uint64_t bits, uint32_t &used) {
+    const uint32_t e = uni(t.fast[(uint32_t)bits & ((1u << INF_FAST) - 1)]);
+    if (e) {
+        used = e & 15;
+        return e >> 4;
+    }
+    uint32_t code = 0, first = 0, index = 0;
+    for (uint32_t l = 1; l <= 15; l++) {
+        code |= (uint32_t)(bits >> (l - 1)) & 1;
+        const uint32_t n = uni(t.count[l]);
+        if (code < first + n) {
+            used = l;
+            return uni(t.sorted[index + (code - first)]);
+        }
+        index += n;
+        first = (first + n) << 1;
+        code <<= 1;
+    }
+    used = 0;
+    return 0;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__restrict__ src, uint64_t src_total,
+                                                            const InflateChunk *__restrict__ chunks, uint32_t n_chunks,
+                                                            uint8_t *__restrict__ dst, uint32_t *__restrict__ sizes) {
+    __shared__ __align__(16) Lds lds;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t chunk = blockIdx.x;
+    if (chunk >= n_chunks) return;
+    const InflateChunk ck = chunks[chunk];
+    const uint32_t src_len = ck.src_len, cap = ck.dst_cap;
+    const uintptr_t in_addr = (uintptr_t)src + ck.src_off;          // the chunk's first byte
+    const uintptr_t src_end = (uintptr_t)src + src_total;
+    uint8_t *const out = dst + ck.dst_off;
+
+    // ---- the bit reader: `n` unread bits in `buf`, the word at chunk offset `pos` comes next ----
+    uint64_t buf = 0;
+    uint32_t n = 0;
+    int64_t pos = 0;          // multiple of 4 as an address (may start below 0: the word the chunk starts in)
+    uintptr_t tile_at = 0;    // address of lds.in[0], a multiple of 16
+    bool tile_ok = false;
+    auto tile_fill = [&](uintptr_t addr) {
+        tile_at = addr & ~(uintptr_t)15;
+        __builtin_amdgcn_wave_barrier();
+        const uintptr_t a = tile_at + (uintptr_t)lane * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (a < src_end) v = *(const uint4 *)a;  // (the 16 bytes around the buffer's ends are read whole)
+        ((uint4 *)lds.in)[lane] = v;
+        lds_fence();
+        tile_ok = true;
+    };
+    auto next_word = [&]() -> uint32_t {  // the 4 bytes at chunk offset pos
+        const uintptr_t a = in_addr + pos;
+        if (!tile_ok || a < tile_at || a + 4 > tile_at + INF_IN) tile_fill(a);
+        return uni(*(const uint32_t *)(lds.in + (a - tile_at)));
+    };
+    auto seek = [&](uint64_t byte) {  // the bit reader starts over at chunk offset `byte`
+        const uint32_t skew = (uint32_t)((in_addr + byte) & 3);
+        pos = (int64_t)byte - skew;
+        const uint32_t w = next_word();
+        buf = (uint64_t)(w >> (8 * skew));
+        n = 32 - 8 * skew;
+        pos += 4;
+    };
+    auto refill = [&]() {  // at least 33 bits afterwards
+        if (n <= 32) {
+            buf |= (uint64_t)next_word() << n;
+            n += 32;
+            pos += 4;
+        }
+    };
+    auto take = [&](uint32_t k) -> uint32_t {  // k <= 32 bits
+        const uint32_t v = (uint32_t)(buf & ((1ull << k) - 1));
+        buf >>= k;
+        n -= k;
+        return v;
+    };
+    auto consumed = [&]() -> int64_t { return 8 * pos - (int64_t)n; };  // bits of the chunk read so far
+    const int64_t limit = 8 * (int64_t)src_len;
+
+    // ---- output: `wpos` bytes so far, the last INF_WIN of them in lds.window, `flushed` in memory ----
+    uint32_t wpos = 0, flushed = 0;
+    auto flush = [&](uint32_t upto) {
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = flushed + lane; i < upto; i += 64) out[i] = lds.window[i & (INF_WIN - 1)];
+        flushed = upto;
+    };
+
+    const uint32_t clen_slot = CLEN_ORDER[lane < 19 ? lane : 0];  // where lane i puts the i-th code-length length
+    bool ok = true, last = false;
+    seek(0);
+    while (ok && !last) {
+        refill();
+        last = take(1) != 0;
+        const uint32_t type = take(2);
+        if (type == 3) {
+            ok = false;
+            break;
+        }
+        if (type == 0) {  // stored: to the next byte, LEN, ~LEN, the bytes
+            take(n & 7);
+            refill();
+            const uint32_t len = take(16), nlen = take(16);
+            const int64_t at = consumed() / 8;
+            if ((len ^ nlen) != 0xFFFF || consumed() > limit || at + len > (int64_t)src_len || len > cap - wpos) {
+                ok = false;
+                break;
+            }
+            for (uint32_t done = 0; done < len;) {
+                const uint32_t piece = len - done < INF_FLUSH ? len - done : INF_FLUSH;
+                for (uint32_t i = lane; i < piece; i += 64)
+                    lds.window[(wpos + i) & (INF_WIN - 1)] = *(const uint8_t *)(in_addr + at + done + i);
+                lds_fence();
+                wpos += piece;
+                done += piece;
+                if (wpos - flushed >= INF_FLUSH) flush(wpos);
+            }
+            seek((uint64_t)(at + len));
+            continue;
+        }
+        // ---- the block's two codes ----
+        if (type == 1) {
+            for (uint32_t i = lane; i < 288; i += 64) lds.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
+            lds_fence();
+            (void)build_table(lds.lit, lds.lens, 288, true, lane);
+            if (lane < 32) lds.lens[lane] = 5;
+            lds_fence();
+            (void)build_table(lds.dist, lds.lens, 32, true, lane);
+        } else {
+            const uint32_t nlen = take(5) + 257, ndist = take(5) + 1, ncode = take(4) + 4;
+            if (nlen > 286 || ndist > 30) {
+                ok = false;
+                break;
+            }
+            if (lane < 19) lds.lens[lane] = 0;
+            lds_fence();
+            for (uint32_t i = 0; i < ncode; i++) {
+                refill();
+                const uint32_t l = take(3);
+                if (lane == i) lds.lens[clen_slot] = (uint8_t)l;
+            }
+            lds_fence();
+            if (!build_table(lds.dist, lds.lens, 19, false, lane)) {  // (the distance table's room, free until below)
+                ok = false;
+                break;
+            }
+            // the code lengths of both codes, as one list
+            uint32_t have = 0, prev = 0;
+            const uint32_t want = nlen + ndist;
+            while (have < want) {
+                refill();
+                uint32_t used;
+                const uint32_t sym = decode_symbol(lds.dist, buf, used);
+                if (!used) {
+                    ok = false;
+                    break;
+                }
+                take(used);
+                if (sym < 16) {
+                    if (lane == 0) lds.lens[32 + have] = (uint8_t)sym;  // (kept clear of the code-length lengths)
+                    prev = sym;
+                    have++;
+                    continue;
+                }
+                uint32_t rep, val = 0;
+                if (sym == 16) {
+                    if (have == 0) {
+                        ok = false;
+                        break;
+                    }
+                    val = prev;
+                    rep = 3 + take(2);
+                } else if (sym == 17) {
+                    rep = 3 + take(3);
+                } else {
+                    rep = 11 + take(7);
+                }
+                if (have + rep > want) {
+                    ok = false;
+                    break;
+                }
+                for (uint32_t i = lane; i < rep; i += 64) lds.lens[32 + have + i] = (uint8_t)val;
+                have += rep;
+                prev = val;
+            }
+            if (!ok || consumed() > limit) {
+                ok = false;
+                break;
+            }
+            lds_fence();
+            if (uni(lds.lens[32 + 256]) == 0) {  // no end-of-block code
+                ok = false;
+                break;
+            }
+            if (!build_table(lds.lit, lds.lens + 32, nlen, true, lane) ||
+                !build_table(lds.dist, lds.lens + 32 + nlen, ndist, true, lane)) {
+                ok = false;
+                break;
+            }
+        }
+        // ---- the block's symbols ----
+        for (;;) {
+            refill();
+            uint32_t used;
+            const uint32_t sym = decode_symbol(lds.lit, buf, used);
+            if (!used) {
+                ok = false;
+                break;
+            }
+            take(used);
+            if (sym < 256) {
+                if (wpos >= cap) {
+                    ok = false;
+                    break;
+                }
+                if (lane == 0) lds.window[wpos & (INF_WIN - 1)] = (uint8_t)sym;
+                wpos++;
+            } else if (sym == 256) {
+                break;
+            } else {
+                if (sym >= 286) {
+                    ok = false;
+                    break;
+                }
+                uint32_t len, dist, extra;
+                length_code(sym - 257, len, extra);
+                len += take(extra);
+                refill();
+                const uint32_t dsym = decode_symbol(lds.dist, buf, used);
+                if (!used || dsym >= 30) {
+                    ok = false;
+                    break;
+                }
+                take(used);
+                distance_code(dsym, dist, extra);
+                dist += take(extra);
+                if (dist > wpos || len > cap - wpos) {
+                    ok = false;
+                    break;
+                }
+                lds_fence();
+                // every source byte was there before the match began: of a match that overlaps
+                // itself, byte i repeats byte i mod dist
+                if (dist >= len) {
+                    for (uint32_t i = lane; i < len; i += 64)
+                        lds.window[(wpos + i) & (INF_WIN - 1)] = lds.window[(wpos - dist + i) & (INF_WIN - 1)];
+                } else {
+                    const float inv = 1.0f / (float)dist;  // (i, dist < 512: the quotient is off by one at most)
+                    for (uint32_t i = lane; i < len; i += 64) {
+                        int32_t r = (int32_t)i - (int32_t)((uint32_t)((float)i * inv) * dist);
+                        if (r < 0) r += (int32_t)dist;
+                        if (r >= (int32_t)dist) r -= (int32_t)dist;
+                        lds.window[(wpos + i) & (INF_WIN - 1)] = lds.window[(wpos - dist + (uint32_t)r) & (INF_WIN - 1)];
+                    }
+                }
+                lds_fence();
+                wpos += len;
+            }
+            if (consumed() > limit) {
+                ok = false;
+                break;
+            }
+            if (wpos - flushed >= INF_FLUSH) flush(wpos);
+        }
+        if (consumed() > limit) ok = false;
+    }
+    if (ok) flush(wpos);
+    if (lane == 0) sizes[chunk] = ok ? wpos : 0xFFFFFFFFu;
+}
+
+hipError_t launch_inflate_chunks(hipStream_t st, const uint8_t *src, uint64_t src_total, const InflateChunk *chunks,
+                                 uint32_t n_chunks, uint8_t *dst, uint32_t *sizes) {
+    if (n_chunks == 0) return hipSuccess;
+    inflate_chunks_kernel<<<n_chunks, 64, 0, st>>>(src, src_total, chunks, n_chunks, dst, sizes);
+    return hipGetLastError();
+}
+
+// Chunks that were not full in their slots, moved to where the stream wants them: piece k of
+// `moves` is copied by one workgroup.
+__global__ __launch_bounds__(256) void inflate_compact_kernel(const uint8_t *__restrict__ from, uint8_t *__restrict__ to,
+                                                              const InflateMove *__restrict__ moves) {
+    const InflateMove m = moves[blockIdx.x];
+    for (uint64_t i = threadIdx.x; i < m.len; i += 256) to[m.to + i] = from[m.from + i];
+}
+
+hipError_t launch_inflate_compact(hipStream_t st, const uint8_t *from, uint8_t *to, const InflateMove *moves,
+                                  uint32_t n_moves) {
+    if (n_moves == 0) return hipSuccess;
+    inflate_compact_kernel<<<n_moves, 256, 0, st>>>(from, to, moves);
+    return hipGetLastError();
+}
+
+}  // namespace orcd

@@ -1147,8 +1147,60 @@ int orcd_rlev2_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num
     return ORCD_OK;
 } ORCD_CATCH
 
-// orcd_rlev2_decode for callers that cannot allocate: device pointers only, every table in the
-// library's static device array, limits instead of growth.
+// The chunks' table to the device, the kernel, the sizes back (waits for the stream).
+int inflate_device(orcd_ctx *c, const uint8_t *d_src, size_t src_len, const orcd_chunk *chunks, size_t n_chunks,
+                   uint8_t *d_dst, size_t dst_len, uint32_t *sizes) {
+    static_assert(sizeof(orcd_chunk) == sizeof(InflateChunk) && offsetof(orcd_chunk, src_length) == offsetof(InflateChunk, src_len) &&
+                  offsetof(orcd_chunk, dst_offset) == offsetof(InflateChunk, dst_off), "one layout");
+    if (n_chunks > 0x7FFFFFFFull) return ORCD_INVALID_ARGUMENT;
+    for (size_t k = 0; k < n_chunks; k++) {
+        const orcd_chunk &ck = chunks[k];
+        if (ck.src_offset > src_len || ck.src_length > src_len - ck.src_offset || ck.dst_offset > dst_len ||
+            ck.dst_capacity > dst_len - ck.dst_offset)
+            return ORCD_INVALID_ARGUMENT;
+    }
+    if (n_chunks == 0) return ORCD_OK;
+    const void *d_chunks;
+    void *d_sizes;
+    ORCD_TRY(stage_in(c, SLOT_GROUPS, chunks, n_chunks * sizeof(orcd_chunk), false, &d_chunks));
+    ORCD_TRY(ensure(c, SLOT_FLAGS, std::max<size_t>(64, n_chunks * sizeof(uint32_t)), &d_sizes));
+    HIP_TRY(c, launch_inflate_chunks(c->stream, d_src, src_len, (const InflateChunk *)d_chunks, (uint32_t)n_chunks, d_dst,
+                                     (uint32_t *)d_sizes));
+    HIP_TRY(c, hipMemcpyAsync(sizes, d_sizes, n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < n_chunks; k++)
+        if (sizes[k] == 0xFFFFFFFFu) return ORCD_DECOMPRESSION;
+    return ORCD_OK;
+}
+
+int orcd_inflate_chunks(orcd_ctx *c, const uint8_t *src, size_t src_len, const orcd_chunk *chunks, size_t n_chunks,
+                        uint8_t *dst, size_t dst_len, uint32_t *sizes, unsigned flags) try {
+    if (!c || (src_len && !src) || (dst_len && !dst) || (n_chunks && (!chunks || !sizes))) return ORCD_INVALID_ARGUMENT;
+    if (n_chunks == 0) return ORCD_OK;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    mark(c, 0);
+    const void *d_src;
+    ORCD_TRY(stage_in(c, SLOT_IN_A, src, src_len, in_dev, &d_src));
+    uint8_t *d_dst = dst;
+    if (!out_dev) {
+        void *p;
+        ORCD_TRY(ensure(c, SLOT_OUT_A, dst_len, &p));
+        d_dst = (uint8_t *)p;
+    }
+    mark(c, 1);
+    const int rc = inflate_device(c, (const uint8_t *)d_src, src_len, chunks, n_chunks, d_dst, dst_len, sizes);
+    mark(c, 3);
+    if (rc != ORCD_OK) return rc;
+    if (!out_dev)  // (only the bytes that were written: the rest of the staging block is not the caller's)
+        for (size_t k = 0; k < n_chunks; k++)
+            if (sizes[k]) HIP_TRY(c, hipMemcpyAsync(dst + chunks[k].dst_offset, d_dst + chunks[k].dst_offset, sizes[k],
+                                                    hipMemcpyDeviceToHost, c->stream));
+    if (!out_dev) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ORCD_OK;
+} ORCD_CATCH
+
 int orcd_rlev1_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_values,
                       const uint64_t *entry_points, size_t n_entries, int64_t *out,
                       unsigned flags) try {
@@ -1175,6 +1227,8 @@ int orcd_rlev1_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num
     return ORCD_OK;
 } ORCD_CATCH
 
+// orcd_rlev2_decode for callers that cannot allocate: device pointers only, every table in the
+// library's static device array, limits instead of growth.
 int orcd_rlev2_decode_noalloc(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_values,
                               const uint64_t *entry_points, size_t n_entries, int64_t *out,
                               unsigned flags) try {
@@ -1899,8 +1953,8 @@ struct ColumnStreams {
     orcd_file *file;
     orcd_column *col;
     const StripeBytes *dev;  // the device copy the column's streams lie in
-    // a compressed file: the column's streams were decompressed on the host (the column handle
-    // holds them, starting at plain_host) and copied to the device as they are (plain_dev)
+    // a compressed file: the column's streams lie decompressed on the device, stream k at
+    // plain_dev + the offset the column handle keeps for it (plain_host: unused)
     const uint8_t *plain_dev = nullptr, *plain_host = nullptr;
     // flags for the stream decoders: streams on the device, ROW_INDEX positions on the host,
     // results stay on the device
@@ -1912,14 +1966,13 @@ struct ColumnStreams {
         *len = 0;
         *entries = nullptr;
         *n_entries = 0;
-        if (plain_host) {
-            const uint8_t *hb = nullptr;
-            size_t hl = 0;
-            const int rc = orcd_column_get_stream(col, kind, &hb, &hl);
+        if (plain_dev) {
+            uint64_t off = 0, n = 0;
+            const int rc = orcd_internal_column_plain_range(col, kind, &off, &n);
             if (rc == ORCD_INVALID_KIND && !required) return ORCD_OK;
             if (rc != ORCD_OK) return rc;
-            *bytes = plain_dev + (hb - plain_host);
-            *len = hl;
+            *bytes = plain_dev + off;
+            *len = (size_t)n;
             return orcd_column_entry_points(file, col, kind, entries, n_entries);
         }
         uint64_t off = 0, n = 0;
@@ -2368,26 +2421,60 @@ struct StreamBatch {
     }
 };
 
-int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
-                       const uint32_t *columns, size_t n_columns, unsigned flags, orcd_column_data *out,
-                       std::vector<std::unique_ptr<StripeJob>> &jobs, Pending &stripe_mem) {
-    // 1. the bytes the columns' streams span, read once and copied once to the device
-    orcd_stripe_info si;
-    ORCD_TRY(orcd_file_stripe(file, stripe, &si));
-    const bool compressed = orcd_file_compression(file) != 0;
+// ---- the columns of a compressed stripe, decompressed, on the device ----------------------------
+// Zlib chunks are inflated by the GPU when the stripe's columns hold enough of them to fill it (a
+// wavefront inflates a chunk at a few megabytes a second; what pays is thousands at once); fewer
+// chunks, and the other codecs, are decompressed by the host's threads and copied over.
+// ORCD_GPU_INFLATE=0 keeps everything on the host, ORCD_GPU_INFLATE_MIN_CHUNKS moves the limit.
+constexpr size_t GPU_INFLATE_MIN_CHUNKS = 1024;
+constexpr uint64_t MOVE_PIECE = 16384;  // bytes one workgroup of the move kernel copies
+
+size_t gpu_inflate_min_chunks() {
+    if (const char *e = getenv("ORCD_GPU_INFLATE"))
+        if (e[0] == '0') return ~(size_t)0;
+    if (const char *e = getenv("ORCD_GPU_INFLATE_MIN_CHUNKS"))
+        if (*e) return (size_t)strtoull(e, nullptr, 10);
+    return GPU_INFLATE_MIN_CHUNKS;
+}
+
+void add_move(std::vector<InflateMove> &moves, uint64_t from, uint64_t to, uint64_t len) {
+    for (uint64_t done = 0; done < len; done += MOVE_PIECE)
+        moves.push_back({from + done, to + done, std::min<uint64_t>(MOVE_PIECE, len - done)});
+}
+
+int run_moves(orcd_ctx *c, const std::vector<InflateMove> &moves, const uint8_t *from, uint8_t *to) {
+    if (moves.empty()) return ORCD_OK;
+    if (moves.size() > 0x7FFFFFFFull) return ORCD_INVALID_ARGUMENT;
+    const void *d_moves;
+    ORCD_TRY(stage_in(c, SLOT_TMP, moves.data(), moves.size() * sizeof(InflateMove), false, &d_moves));
+    HIP_TRY(c, launch_inflate_compact(c->stream, from, to, (const InflateMove *)d_moves, (uint32_t)moves.size()));
+    return ORCD_OK;
+}
+
+int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::unique_ptr<StripeJob>> &jobs,
+                                 size_t n_columns, Pending &stripe_mem) {
+    struct Raw {
+        const uint8_t *bytes;
+        size_t len, n_chunks, n_streams;
+        const orcd_internal_chunk *chunks;
+        uint64_t at;  // where the region lies in the device copy
+    };
+    std::vector<Raw> raw(n_columns);
+    size_t deflated = 0;
+    uint64_t raw_total = 0;
     for (size_t i = 0; i < n_columns; i++) {
-        if (columns[i] >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
-        (*jobs[i]).type_kind = orcd_file_type_kind(file, columns[i]);
-        // (a compressed file: the host reads each column's region and inflates its streams,
-        // src/read/decompress/mod.rs:60-80, and the decompressed streams are what goes to the GPU)
-        if (compressed) ORCD_TRY(orcd_read_stripe_column(file, stripe, footer, columns[i], &(*jobs[i]).col));
-        else ORCD_TRY(orcd_stripe_column_open(file, stripe, footer, columns[i], &(*jobs[i]).col));
+        Raw &r = raw[i];
+        ORCD_TRY(orcd_internal_column_raw((*jobs[i]).col, &r.bytes, &r.len, &r.chunks, &r.n_chunks, &r.n_streams));
+        for (size_t j = 0; j < r.n_chunks; j++) deflated += (!r.chunks[j].original && r.chunks[j].len);
+        r.at = raw_total;
+        raw_total += (r.len + 255) & ~(uint64_t)255;
     }
-    StripeBytes sb;
-    if (compressed) {
+    if (orcd_file_compression(file) != 1 || deflated < gpu_inflate_min_chunks()) {
+        // the host's threads decompress; the plain streams go to the device as they are
         uint64_t total = 0;
         std::vector<uint64_t> at(n_columns);
         for (size_t i = 0; i < n_columns; i++) {
+            ORCD_TRY(orcd_internal_column_inflate_host(file, (*jobs[i]).col));
             const uint8_t *hb;
             size_t hl;
             ORCD_TRY(orcd_internal_column_bytes((*jobs[i]).col, &hb, &hl));
@@ -2399,14 +2486,128 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
             const uint8_t *hb;
             size_t hl;
             ORCD_TRY(orcd_internal_column_bytes((*jobs[i]).col, &hb, &hl));
-            (*jobs[i]).plain_host = hb;
             (*jobs[i]).plain_dev = (const uint8_t *)stripe_mem.tmp + at[i];
             if (hl) {
                 const HostSource src = {nullptr, 0, hb};
                 ORCD_TRY(chunked_to_device(c, src, hl, (uint8_t *)stripe_mem.tmp + at[i]));
             }
         }
+        return ORCD_OK;
     }
+
+    // every chunk gets a place of its own: a deflated one the file's compression block size (the
+    // most it may decompress to), a stored one its length; a stream's chunks lie back to back
+    uint64_t block = orcd_internal_file_compression_block(file);
+    if (block > (1ull << 30)) block = 1ull << 30;  // (whatever the PostScript claims)
+    std::vector<orcd_chunk> work;
+    std::vector<InflateMove> stored;
+    std::vector<std::vector<uint64_t>> place(n_columns);
+    uint64_t plain_total = 0;
+    for (size_t i = 0; i < n_columns; i++) {
+        const Raw &r = raw[i];
+        place[i].resize(r.n_chunks);
+        uint32_t stream = ~0u;
+        for (size_t j = 0; j < r.n_chunks; j++) {
+            const orcd_internal_chunk &ch = r.chunks[j];
+            if (ch.stream != stream) {
+                plain_total = (plain_total + 15) & ~(uint64_t)15;  // streams start 16-byte aligned
+                stream = ch.stream;
+            }
+            place[i][j] = plain_total;
+            if (ch.original) {
+                add_move(stored, r.at + ch.at, plain_total, ch.len);
+                plain_total += ch.len;
+            } else if (ch.len) {
+                orcd_chunk w;
+                w.src_offset = r.at + ch.at;
+                w.dst_offset = plain_total;
+                w.src_length = ch.len;
+                w.dst_capacity = (uint32_t)block;
+                work.push_back(w);
+                plain_total += block;
+            }
+        }
+    }
+    Pending hold(c);  // the compressed bytes: done with when the sizes are back
+    ORCD_TRY(dev_alloc(c, std::max<uint64_t>(raw_total, 256), &hold.tmp));
+    ORCD_TRY(dev_alloc(c, std::max<uint64_t>(plain_total, 256), &stripe_mem.tmp));
+    for (size_t i = 0; i < n_columns; i++) {
+        if (!raw[i].len) continue;
+        const HostSource src = {nullptr, 0, raw[i].bytes};
+        ORCD_TRY(chunked_to_device(c, src, raw[i].len, (uint8_t *)hold.tmp + raw[i].at));
+    }
+    ORCD_TRY(run_moves(c, stored, (const uint8_t *)hold.tmp, (uint8_t *)stripe_mem.tmp));
+    std::vector<uint32_t> sizes(work.size());
+    ORCD_TRY(inflate_device(c, (const uint8_t *)hold.tmp, raw_total, work.data(), work.size(), (uint8_t *)stripe_mem.tmp,
+                            plain_total, sizes.data()));  // (waits for the stream)
+
+    // where everything came to lie; a chunk that did not fill its place -- other than a stream's
+    // last -- leaves a gap, and then the chunks are moved together
+    bool gaps = false;
+    {
+        size_t w = 0;
+        for (size_t i = 0; i < n_columns && !gaps; i++) {
+            const Raw &r = raw[i];
+            for (size_t j = 0; j < r.n_chunks; j++) {
+                const orcd_internal_chunk &ch = r.chunks[j];
+                if (ch.original || !ch.len) continue;
+                const bool last = j + 1 == r.n_chunks || r.chunks[j + 1].stream != ch.stream;
+                if (sizes[w++] != block && !last) gaps = true;
+            }
+        }
+    }
+    std::vector<InflateMove> moves;
+    uint64_t tight_total = 0;
+    size_t w = 0;
+    for (size_t i = 0; i < n_columns; i++) {
+        const Raw &r = raw[i];
+        std::vector<uint64_t> plain_off(r.n_streams, 0), plain_len(r.n_streams, 0), chunk_off(r.n_chunks, 0);
+        uint32_t stream = ~0u;
+        for (size_t j = 0; j < r.n_chunks; j++) {
+            const orcd_internal_chunk &ch = r.chunks[j];
+            const uint64_t size = ch.original ? ch.len : (ch.len ? sizes[w++] : 0);
+            if (ch.stream != stream) {
+                stream = ch.stream;
+                tight_total = (tight_total + 15) & ~(uint64_t)15;
+                plain_off[stream] = gaps ? tight_total : place[i][j];
+            }
+            chunk_off[j] = plain_len[stream];
+            if (gaps) add_move(moves, place[i][j], tight_total, size);
+            plain_len[stream] += size;
+            tight_total += size;
+        }
+        // (a stream without chunks is empty, wherever it lies)
+        ORCD_TRY(orcd_internal_column_set_plain((*jobs[i]).col, plain_off.data(), plain_len.data(), chunk_off.data()));
+    }
+    if (gaps) {
+        void *tight = nullptr;
+        ORCD_TRY(dev_alloc(c, std::max<uint64_t>(tight_total, 256), &tight));
+        hold.tmp2 = stripe_mem.tmp;  // the places: released when the moves are done
+        stripe_mem.tmp = tight;
+        ORCD_TRY(run_moves(c, moves, (const uint8_t *)hold.tmp2, (uint8_t *)tight));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    for (size_t i = 0; i < n_columns; i++) (*jobs[i]).plain_dev = (const uint8_t *)stripe_mem.tmp;
+    return ORCD_OK;
+}
+
+int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
+                       const uint32_t *columns, size_t n_columns, unsigned flags, orcd_column_data *out,
+                       std::vector<std::unique_ptr<StripeJob>> &jobs, Pending &stripe_mem) {
+    // 1. the bytes the columns' streams span, read once and copied once to the device
+    orcd_stripe_info si;
+    ORCD_TRY(orcd_file_stripe(file, stripe, &si));
+    const bool compressed = orcd_file_compression(file) != 0;
+    for (size_t i = 0; i < n_columns; i++) {
+        if (columns[i] >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
+        (*jobs[i]).type_kind = orcd_file_type_kind(file, columns[i]);
+        // (a compressed file: the host reads each column's region and finds its compression chunks;
+        // they are decompressed below, src/read/decompress/mod.rs:60-80, on the device or the host)
+        if (compressed) ORCD_TRY(orcd_internal_read_column_raw(file, stripe, footer, columns[i], &(*jobs[i]).col));
+        else ORCD_TRY(orcd_stripe_column_open(file, stripe, footer, columns[i], &(*jobs[i]).col));
+    }
+    StripeBytes sb;
+    if (compressed) ORCD_TRY(compressed_columns_to_device(c, file, jobs, n_columns, stripe_mem));
     sb.lo = ~0ull;
     for (size_t i = 0; i < n_columns && !compressed; i++) {
         uint64_t off = 0, n = 0;

@@ -1,0 +1,29 @@
+// What the column calls (orcd_api.hip) and the host reader (orcd_host.cpp) share beyond
+// include/orcd.h: the bytes a column handle holds, and the way of a compressed column whose chunks
+// are decompressed by the caller.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/orcd.h"
+
+extern "C" int orcd_internal_column_bytes(const orcd_column *col, const uint8_t **bytes, size_t *len);
+// One compression chunk of a column region read as it is in the file.
+struct orcd_internal_chunk {
+    uint64_t header;    // offset of the chunk's 3-byte header in its (compressed) stream
+    uint64_t at;        // offset of its first byte in the region
+    uint32_t len;
+    uint32_t stream;    // which of the column's non-ROW_INDEX streams, in file order
+    uint32_t original;  // stored as it is
+    uint32_t pad;
+};
+extern "C" int orcd_internal_read_column_raw(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft, uint32_t column,
+                                             orcd_column **out);
+extern "C" int orcd_internal_column_raw(const orcd_column *col, const uint8_t **bytes, size_t *len,
+                                        const orcd_internal_chunk **chunks, size_t *n_chunks, size_t *n_streams);
+extern "C" int orcd_internal_column_inflate_host(orcd_file *f, orcd_column *col);
+extern "C" int orcd_internal_column_set_plain(orcd_column *col, const uint64_t *plain_off, const uint64_t *plain_len,
+                                              const uint64_t *chunk_off);
+extern "C" int orcd_internal_column_plain_range(const orcd_column *col, int kind, uint64_t *off, uint64_t *len);
+extern "C" uint64_t orcd_internal_file_compression_block(const orcd_file *f);

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <new>
 #include <thread>
 #include <string>
@@ -19,6 +20,7 @@
 #include <zlib.h>
 
 #include "../../include/orcd.h"
+#include "orcd_column_internal.h"
 
 // No exception leaves the C ABI: host allocations (std::vector, new) are what throws here.
 #define ORCD_CATCH                                     \
@@ -169,6 +171,11 @@ struct orcd_column {
     bool compressed = false;
     std::vector<uint64_t> plain_off, plain_len;
     std::vector<std::vector<std::pair<uint64_t, uint64_t>>> chunks;
+    // In between (the column calls, which may inflate on the device): `data` holds the column's
+    // region as it is in the file, `raw_chunks` every compression chunk of it in file order.
+    bool raw = false;
+    std::vector<orcd_internal_chunk> raw_chunks;
+    uint32_t raw_streams = 0;
     uint32_t column = 0;
     uint64_t number_of_rows = 0;
     size_t stripe = 0;
@@ -741,6 +748,7 @@ int orcd_file_stripe(const orcd_file *f, size_t stripe, orcd_stripe_info *info) 
 } ORCD_CATCH
 
 int orcd_file_compression(const orcd_file *f) { return f ? f->compression : -1; }
+uint64_t orcd_internal_file_compression_block(const orcd_file *f) { return f ? f->compression_block : 0; }
 uint64_t orcd_file_number_of_rows(const orcd_file *f) { return f ? f->number_of_rows : 0; }
 uint32_t orcd_file_row_index_stride(const orcd_file *f) { return f ? f->row_index_stride : 0; }
 size_t orcd_file_num_types(const orcd_file *f) { return f ? f->types.size() : 0; }
@@ -784,13 +792,13 @@ int orcd_stripe_footer_stream(const orcd_stripe_footer *ft, size_t i, orcd_strea
     return ORCD_OK;
 } ORCD_CATCH
 
-int orcd_read_stripe_column(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft,
-                            uint32_t column, orcd_column **out) try {
+// The column's region read as it is in the file (src/read/mod.rs:129-144).
+static int read_column_region(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft, uint32_t column,
+                              orcd_column **out) {
     if (!f || !ft || !out) return ORCD_INVALID_ARGUMENT;
     *out = nullptr;
     if (stripe >= f->stripes.size()) return ORCD_INVALID_ARGUMENT;
     // first non-ROW_INDEX stream of the column and the total length of all of them
-    // (src/read/mod.rs:129-144)
     bool found = false;
     uint64_t start = 0, length = 0;
     for (const auto &s : ft->streams) {
@@ -804,43 +812,153 @@ int orcd_read_stripe_column(orcd_file *f, size_t stripe, const orcd_stripe_foote
     if (!found) return ORCD_INVALID_COLUMN;
     uint64_t region_at;
     if (!add_ok(f->stripes[stripe].offset, start, region_at)) return ORCD_OUT_OF_SPEC;
-    orcd_column *col = new orcd_column();
-    if (!f->src.read_at(region_at, length, col->data)) {
-        delete col;
-        return ORCD_OUT_OF_SPEC;
-    }
+    std::unique_ptr<orcd_column> col(new orcd_column());
+    if (!f->src.read_at(region_at, length, col->data)) return ORCD_OUT_OF_SPEC;
     col->column = column;
     col->number_of_rows = f->stripes[stripe].number_of_rows;
     col->stripe = stripe;
     col->footer = ft;
+    *out = col.release();
+    return ORCD_OK;
+}
+
+// Every stream of a compressed file is a chain of compression chunks of its own
+// (src/read/column.rs:38-55 wraps the stream's slice in a Decompressor): they are decompressed
+// here, back to back, and take the place of the region in `data`.
+static int inflate_column(orcd_file *f, orcd_column *col) {
+    std::vector<uint8_t> plain;
+    uint64_t start2 = 0;
+    col->plain_off.clear();
+    col->plain_len.clear();
+    col->chunks.clear();
+    for (const auto &s : col->footer->streams) {
+        if (s.column != col->column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
+        if (start2 > col->data.size() || s.length > col->data.size() - start2) return ORCD_OUT_OF_SPEC;
+        while (plain.size() & 15) plain.push_back(0);  // streams start 16-byte aligned
+        col->plain_off.push_back(plain.size());
+        col->chunks.emplace_back();
+        const int rc = inflate_chunks(f->compression, col->data.data() + start2, (size_t)s.length, f->compression_block, plain, &col->chunks.back());
+        if (rc != ORCD_OK) return rc;
+        col->plain_len.push_back(plain.size() - col->plain_off.back());
+        start2 += s.length;
+    }
+    col->data.swap(plain);
+    col->compressed = true;
+    col->raw = false;
+    col->raw_chunks.clear();
+    return ORCD_OK;
+}
+
+int orcd_read_stripe_column(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft,
+                            uint32_t column, orcd_column **out) try {
+    orcd_column *col = nullptr;
+    const int rc = read_column_region(f, stripe, ft, column, &col);
+    if (rc != ORCD_OK) return rc;
     if (f->compression != 0) {
-        // every stream is a chain of compression chunks of its own (src/read/column.rs:38-55 wraps
-        // the stream's slice in a Decompressor): decompress them all now, back to back
-        std::vector<uint8_t> plain;
-        uint64_t start2 = 0;
-        for (const auto &s : ft->streams) {
-            if (s.column != column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
-            if (start2 > col->data.size() || s.length > col->data.size() - start2) {
-                delete col;
-                return ORCD_OUT_OF_SPEC;
-            }
-            while (plain.size() & 15) plain.push_back(0);  // streams start 16-byte aligned
-            col->plain_off.push_back(plain.size());
-            col->chunks.emplace_back();
-            const int rc = inflate_chunks(f->compression, col->data.data() + start2, (size_t)s.length, f->compression_block, plain, &col->chunks.back());
-            if (rc != ORCD_OK) {
-                delete col;
-                return rc;
-            }
-            col->plain_len.push_back(plain.size() - col->plain_off.back());
-            start2 += s.length;
+        const int irc = inflate_column(f, col);
+        if (irc != ORCD_OK) {
+            delete col;
+            return irc;
         }
-        col->data.swap(plain);
-        col->compressed = true;
     }
     *out = col;
     return ORCD_OK;
 } ORCD_CATCH
+
+// ---- (not part of include/orcd.h) the column calls' way through a compressed file ----
+// The region as it is, and the table of its compression chunks (headers walked, nothing
+// decompressed): what happens to the chunks next is up to the caller -- inflate them on the
+// device and report the sizes (orcd_internal_column_set_plain), or leave it to the host
+// (orcd_internal_column_inflate_host).
+int orcd_internal_read_column_raw(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft, uint32_t column,
+                                  orcd_column **out) try {
+    orcd_column *col = nullptr;
+    const int rc = read_column_region(f, stripe, ft, column, &col);
+    if (rc != ORCD_OK) return rc;
+    std::unique_ptr<orcd_column> hold(col);
+    if (f->compression == 0) return ORCD_INVALID_ARGUMENT;
+    uint64_t start = 0;
+    uint32_t k = 0;
+    for (const auto &s : ft->streams) {
+        if (s.column != column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
+        if (start > col->data.size() || s.length > col->data.size() - start) return ORCD_OUT_OF_SPEC;
+        const uint8_t *src = col->data.data() + start;
+        const size_t n = (size_t)s.length;
+        for (size_t pos = 0; pos < n;) {  // (the walk of inflate_chunks)
+            if (n - pos < 3) return ORCD_DECOMPRESSION;
+            const uint32_t h = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
+            const size_t len = h >> 1;
+            if (len > n - pos - 3) return ORCD_DECOMPRESSION;
+            orcd_internal_chunk c;
+            c.header = pos;
+            c.at = start + pos + 3;
+            c.len = (uint32_t)len;
+            c.stream = k;
+            c.original = h & 1;
+            c.pad = 0;
+            col->raw_chunks.push_back(c);
+            pos += 3 + len;
+        }
+        start += s.length;
+        k++;
+    }
+    col->raw = true;
+    col->raw_streams = k;
+    *out = hold.release();
+    return ORCD_OK;
+} ORCD_CATCH
+
+int orcd_internal_column_raw(const orcd_column *col, const uint8_t **bytes, size_t *len,
+                             const orcd_internal_chunk **chunks, size_t *n_chunks, size_t *n_streams) {
+    if (!col || !col->raw) return ORCD_INVALID_ARGUMENT;
+    *bytes = col->data.data();
+    *len = col->data.size();
+    *chunks = col->raw_chunks.data();
+    *n_chunks = col->raw_chunks.size();
+    *n_streams = col->raw_streams;
+    return ORCD_OK;
+}
+
+int orcd_internal_column_inflate_host(orcd_file *f, orcd_column *col) try {
+    if (!f || !col || !col->raw) return ORCD_INVALID_ARGUMENT;
+    return inflate_column(f, col);
+} ORCD_CATCH
+
+// The chunks were decompressed elsewhere: stream k's bytes start at plain_off[k] of the caller's
+// buffer and are plain_len[k] long, chunk j (in raw_chunks order) starts chunk_off[j] bytes into
+// its stream.  The handle keeps the tables (ROW_INDEX positions need them) and drops the bytes.
+int orcd_internal_column_set_plain(orcd_column *col, const uint64_t *plain_off, const uint64_t *plain_len,
+                                   const uint64_t *chunk_off) try {
+    if (!col || !col->raw) return ORCD_INVALID_ARGUMENT;
+    col->plain_off.assign(plain_off, plain_off + col->raw_streams);
+    col->plain_len.assign(plain_len, plain_len + col->raw_streams);
+    col->chunks.assign(col->raw_streams, {});
+    for (size_t j = 0; j < col->raw_chunks.size(); j++)
+        col->chunks[col->raw_chunks[j].stream].push_back({col->raw_chunks[j].header, chunk_off[j]});
+    col->compressed = true;
+    col->raw = false;
+    col->has_data = false;
+    std::vector<uint8_t>().swap(col->data);
+    std::vector<orcd_internal_chunk>().swap(col->raw_chunks);
+    return ORCD_OK;
+} ORCD_CATCH
+
+// Where a stream's decompressed bytes lie (offset from the start of the decompressed column).
+int orcd_internal_column_plain_range(const orcd_column *col, int kind, uint64_t *off, uint64_t *len) {
+    if (!col || !col->compressed) return ORCD_INVALID_ARGUMENT;
+    size_t k = 0;
+    for (const auto &s : col->footer->streams) {
+        if (s.column != col->column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
+        if ((int)s.kind == kind) {
+            if (k >= col->plain_off.size()) return ORCD_OUT_OF_SPEC;
+            *off = col->plain_off[k];
+            *len = col->plain_len[k];
+            return ORCD_OK;
+        }
+        k++;
+    }
+    return ORCD_INVALID_KIND;
+}
 
 void orcd_column_free(orcd_column *col) { delete col; }
 

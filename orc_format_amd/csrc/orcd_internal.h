@@ -103,7 +103,7 @@ struct ByteRun {
 // (orcd_host.cpp, not part of include/orcd.h) the bytes a column handle holds: its region of the
 // file, or for a compressed file its streams decompressed and 16-byte aligned, back to back --
 // what orcd_column_get_stream points into.
-extern "C" int orcd_internal_column_bytes(const orcd_column *col, const uint8_t **bytes, size_t *len);
+#include "orcd_column_internal.h"
 
 // ---- launchers (defined in the .hip files, called from the C ABI layer) ---------------------
 struct SegTable;  // seg_scan.h
@@ -173,6 +173,22 @@ struct Rlev2Table {
 };
 // Integer RLE version 1 (rlev2.hip, last section): values per segment into `t` (then the segment
 // scan), and -- the same walk again -- the values themselves at the segments' offsets.
+// ---- inflate.hip: the compression chunks of a zlib file, a wavefront each ----
+struct InflateChunk {
+    uint64_t src_off;   // first byte of the raw deflate stream
+    uint64_t dst_off;   // where its output goes
+    uint32_t src_len;
+    uint32_t dst_cap;   // most it may decompress to
+};
+struct InflateMove {
+    uint64_t from, to, len;
+};
+// sizes[k]: bytes chunk k decompressed to, 0xFFFFFFFF when it does not inflate
+hipError_t launch_inflate_chunks(hipStream_t st, const uint8_t *src, uint64_t src_total, const InflateChunk *chunks,
+                                 uint32_t n_chunks, uint8_t *dst, uint32_t *sizes);
+hipError_t launch_inflate_compact(hipStream_t st, const uint8_t *from, uint8_t *to, const InflateMove *moves,
+                                  uint32_t n_moves);
+
 hipError_t launch_rlev1_count(hipStream_t st, const uint8_t *stream, uint64_t len, const uint64_t *entries,
                               uint32_t n_seg, int is_signed, const SegTable &t);
 hipError_t launch_rlev1_emit(hipStream_t st, const uint8_t *stream, uint64_t len, const uint64_t *entries,

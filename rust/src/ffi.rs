@@ -73,6 +73,17 @@ pub struct orcd_run {
     pub reserved: u32,
 }
 
+/// One compression chunk for orcd_inflate_chunks (include/orcd.h; a chunk of
+/// src/read/decompress/mod.rs:60-80 by its place in the source and in the output).
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct orcd_chunk {
+    pub src_offset: u64,
+    pub dst_offset: u64,
+    pub src_length: u32,
+    pub dst_capacity: u32,
+}
+
 /// One run of a byte-RLE stream (include/orcd.h; BooleanRun of src/read/decode/boolean_rle.rs:7-12
 /// as positions in the stream and in the decoded bytes).
 #[repr(C)]
@@ -144,6 +155,9 @@ extern "C" {
     pub fn orcd_rlev2_decode(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_values: usize,
                              entry_points: *const u64, n_entries: usize, out: *mut i64,
                              flags: c_uint) -> c_int;
+    pub fn orcd_inflate_chunks(ctx: *mut orcd_ctx, src: *const u8, src_len: usize,
+                               chunks: *const orcd_chunk, n_chunks: usize, dst: *mut u8,
+                               dst_len: usize, sizes: *mut u32, flags: c_uint) -> c_int;
     pub fn orcd_rlev1_decode(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_values: usize,
                              entry_points: *const u64, n_entries: usize, out: *mut i64,
                              flags: c_uint) -> c_int;

@@ -1,0 +1,145 @@
+"""Compression chunks inflated on the GPU (orcd_inflate_chunks) against zlib: the crate hands each
+chunk to flate2 (src/read/decompress/mod.rs:60-80); Python's zlib module is the same library and
+is the checker here -- same bytes, and the same chunks refused."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from orc_format_amd import default_context
+    return default_context()
+
+
+def deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    return c.compress(data) + c.flush()
+
+
+def cpu_inflate(raw, cap):
+    """(ok, bytes) the way the host path takes a chunk: a complete raw deflate stream of at most
+    `cap` bytes; trailing input is ignored."""
+    d = zlib.decompressobj(-15)
+    try:
+        out = d.decompress(raw, cap + 1)
+    except zlib.error:
+        return False, b""
+    if len(out) > cap or not d.eof:
+        return False, b""
+    return True, out
+
+
+def run(ctx, raws, cap):
+    """Inflates the chunks `raws` in one call, packed back to back with odd gaps."""
+    from orc_format_amd.error import OrcError
+    src = bytearray()
+    chunks = []
+    for k, r in enumerate(raws):
+        src += b"\x5a" * (k % 5)   # every alignment
+        chunks.append((len(src), len(r), k * (cap + 3), cap))
+        src += r
+    try:
+        out, sizes = ctx.inflate_chunks(bytes(src) if src else b"\0", chunks, len(raws) * (cap + 3))
+    except OrcError as e:
+        return e.code, None
+    return 0, [out[k * (cap + 3):k * (cap + 3) + int(sizes[k])].tobytes() for k in range(len(raws))]
+
+
+def samples(rng):
+    text = (b"the quick brown fox jumps over the lazy dog. " * 400)
+    yield b""
+    yield b"a"
+    yield b"abc" * 5
+    yield bytes(1000)
+    yield text
+    yield rng.integers(0, 256, size=70_000, dtype=np.uint8).tobytes()            # stored blocks
+    yield rng.integers(0, 4, size=200_000, dtype=np.uint8).tobytes()              # short codes
+    yield np.cumsum(rng.integers(-2, 3, size=60_000)).astype(np.int64).tobytes()  # integer columns
+    yield rng.integers(0, 2**40, size=30_000).astype(np.int64).tobytes()
+    yield bytes(rng.integers(97, 123, size=1 << 18, dtype=np.uint8)) + text       # > the window
+    yield (b"x" * 100_000) + bytes(rng.integers(0, 256, size=3000, dtype=np.uint8)) * 30   # long distances
+
+
+def test_streams_of_every_kind_decompress_to_what_zlib_gives(ctx):
+    rng = np.random.default_rng(1)
+    raws, want = [], []
+    for data in samples(rng):
+        for level, strategy in ((6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (0, zlib.Z_DEFAULT_STRATEGY)):
+            raws.append(deflate(data, level, strategy))
+            want.append(data)
+    cap = max(len(w) for w in want)
+    rc, got = run(ctx, raws, cap)
+    assert rc == 0
+    for k in range(len(raws)):
+        assert got[k] == want[k], k
+    # trailing bytes after the last block are ignored, as by the host path
+    rc, got = run(ctx, [r + b"\xff\x00\x12" for r in raws[:20]], cap)
+    assert rc == 0 and got == want[:20]
+
+
+def test_room_and_truncation(ctx):
+    data = b"hello world, " * 1000
+    raw = deflate(data)
+    assert run(ctx, [raw], len(data))[0] == 0
+    assert run(ctx, [raw], len(data) - 1)[0] == 6         # ORCD_DECOMPRESSION: more than the room
+    for cut in (1, 2, len(raw) // 2, len(raw) - 1):
+        ok, _ = cpu_inflate(raw[:cut], len(data))
+        assert not ok
+        assert run(ctx, [raw[:cut]], len(data))[0] == 6, cut
+    stored = deflate(data, 0)
+    assert run(ctx, [stored[:-1]], len(data))[0] == 6
+    assert run(ctx, [stored], len(data))[1] == [data]
+
+
+def test_damaged_chunks_are_refused_exactly_when_zlib_refuses_them(ctx):
+    rng = np.random.default_rng(2)
+    base = []
+    for data in list(samples(rng))[1:9]:
+        data = data[:20_000]
+        for level, strategy in ((6, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY)):
+            base.append(deflate(data, level, strategy))
+    cap = 1 << 16
+    ok = bad = 0
+    for round_ in range(6):
+        raws = []
+        for raw in base:
+            m = bytearray(raw)
+            kind = int(rng.integers(0, 4))
+            if kind == 0:      # a bit flipped, early (headers, code lengths) or anywhere
+                at = int(rng.integers(0, min(len(m), 40 if round_ % 2 else len(m))))
+                m[at] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:    # a byte replaced
+                m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+            elif kind == 2:    # cut short
+                m = m[:int(rng.integers(0, len(m)))]
+            else:              # bytes dropped from the middle
+                at = int(rng.integers(0, len(m)))
+                del m[at:at + int(rng.integers(1, 4))]
+            raws.append(bytes(m) if m else b"\x03")
+        # one call per chunk: a call reports the failure of any of its chunks
+        for raw in raws:
+            want_ok, want = cpu_inflate(raw, cap)
+            rc, got = run(ctx, [raw], cap)
+            assert (rc == 0) == want_ok, (round_, raw[:40].hex(), rc)
+            if want_ok:
+                assert got[0] == want
+                ok += 1
+            else:
+                assert rc == 6
+                bad += 1
+    assert ok > 5 and bad > 50
+
+
+def test_many_chunks_in_one_call(ctx):
+    rng = np.random.default_rng(3)
+    block = 1 << 16
+    col = np.cumsum(rng.integers(-3, 4, size=(1 << 21))).astype(np.int64).tobytes()
+    pieces = [col[i:i + block] for i in range(0, len(col), block)]
+    raws = [deflate(p) for p in pieces]
+    rc, got = run(ctx, raws, block)
+    assert rc == 0 and got == pieces

@@ -10,6 +10,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["host", "device"])
+def inflate_where(request, monkeypatch):
+    """Every test twice: the chunks inflated by the host's zlib, and by the GPU (which by itself
+    takes over only when a stripe holds many chunks)."""
+    if request.param == "host":
+        monkeypatch.setenv("ORCD_GPU_INFLATE", "0")
+    else:
+        monkeypatch.setenv("ORCD_GPU_INFLATE_MIN_CHUNKS", "1")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def ctx():
     from orc_format_amd import default_context
