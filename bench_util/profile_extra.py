@@ -152,67 +152,55 @@ def rlev1(ctx):
 
 
 def inflate(ctx):
-    """Compression chunks of zlib files inflated on the device: 64 MiB of column bytes (slowly varying
-    64-bit integers as RLE v2 would leave them, and text) cut into chunks of the compression block
-    size, deflated at level 6, the set repeated to 256 MiB; beside it zlib on one host core."""
-    import ctypes as C
+    """Compression chunks of zlib files inflated on the device: 48 MiB each of three kinds of column
+    bytes -- slowly varying 32-bit integers, doubles rounded to three decimals, text -- cut into
+    chunks of the compression block size, deflated at level 6, the set repeated four times; beside
+    it zlib on one host core."""
     import zlib
     rng = np.random.default_rng(4)
-    ints = np.cumsum(rng.integers(-40, 41, size=1 << 22)).astype(">i4").tobytes()       # 16 MiB
+    size = 48 << 20
+    ints = np.cumsum(rng.integers(-40, 41, size=size // 4)).astype(">i4").tobytes()
+    reals = np.round(rng.standard_normal(size // 8) * 100, 3).tobytes()
     words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 12)), dtype=np.uint8)) for _ in range(5000)]
-    text = b" ".join(words[int(k)] for k in rng.integers(0, len(words), size=1 << 22))[:48 << 20]
-    data = ints + text
-    data = data[:len(data) & ~((1 << 18) - 1)]   # whole blocks of either size
+    text = b" ".join(words[int(k)] for k in rng.integers(0, len(words), size=size // 5))[:size]
+    assert len(text) == size
     lib = N.lib()
-    for block in (1 << 16, 1 << 18):
-        pieces = [data[i:i + block] for i in range(0, len(data), block)]
-        raws = []
-        for p in pieces:
-            c = zlib.compressobj(6, zlib.DEFLATED, -15)
-            raws.append(c.compress(p) + c.flush())
-        t0 = time.perf_counter()
-        for r in raws[:64]:
-            zlib.decompressobj(-15).decompress(r)
-        host = sum(len(p) for p in pieces[:64]) / (time.perf_counter() - t0)
-        reps = 4
-        src = b"".join(raws)
-        table = np.zeros(len(raws) * reps, dtype=[("src_offset", "<u8"), ("dst_offset", "<u8"),
-                                                  ("src_length", "<u4"), ("dst_capacity", "<u4")])
-        at = 0
-        k = 0
-        for rep in range(reps):
-            at = 0
-            for r in raws:
-                table[k] = (rep * len(src) + at, k * block, len(r), block)
-                at += len(r)
-                k += 1
-        d_src = torch.from_numpy(np.frombuffer(src, dtype=np.uint8).copy()).cuda().repeat(reps)
-        d_dst = torch.zeros(len(table) * block, dtype=torch.uint8, device="cuda")
-        sizes = np.zeros(len(table), dtype=np.uint32)
-        dt = timed(ctx, lambda: check(lib.orcd_inflate_chunks(
-            ctx.handle, d_src.data_ptr(), d_src.numel(), table.ctypes.data, len(table), d_dst.data_ptr(),
-            d_dst.numel(), sizes.ctypes.data, N.IN_DEVICE | N.OUT_DEVICE), ctx.handle))
-        want = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
-        total = int(sizes.sum())
-        assert total == len(data) * reps
-        for rep in range(reps):
-            got = d_dst[rep * len(data):(rep + 1) * len(data)]
-            if not torch.equal(got, want):
-                bad = torch.nonzero(got != want).flatten()
-                first = int(bad[0])
-                print("mismatch: rep", rep, "count", bad.numel(), "first", first, "chunk", first // block,
-                      "offset in chunk", first % block, "last", int(bad[-1]),
-                      got[first:first + 16].tolist(), want[first:first + 16].tolist(), flush=True)
-                chunks_bad = torch.unique(bad // block)
-                print("bad chunks", chunks_bad.numel(), chunks_bad[:8].tolist(), chunks_bad[-8:].tolist(), flush=True)
-                cb = chunks_bad.cpu().numpy() + rep * len(raws)
-                print("sizes of bad", sizes[cb][:8], "src off", table["src_offset"][cb][:4], table["src_offset"][cb][:4] % 16,
-                      "dst", table["dst_offset"][cb][:4], flush=True)
-                nz = torch.nonzero(got[bad] != 0).numel()
-                print("nonzero among bad bytes", nz, flush=True)
-        print("inflate: block %d KiB, %d chunks, %.1f MB deflate -> %.1f MB: %.3f ms, %.1f GB/s decompressed "
-              "(zlib on one host core: %.2f GB/s)" % (block >> 10, len(table), d_src.numel() / 1e6, total / 1e6,
-                                                       dt * 1e3, total / dt / 1e9, host / 1e9), flush=True)
+    for name, data in (("integers", ints), ("doubles", reals), ("text", text)):
+        for block in (1 << 16, 1 << 18):
+            pieces = [data[i:i + block] for i in range(0, len(data), block)]
+            raws = []
+            for p in pieces:
+                c = zlib.compressobj(6, zlib.DEFLATED, -15)
+                raws.append(c.compress(p) + c.flush())
+            t0 = time.perf_counter()
+            for r in raws[:64]:
+                zlib.decompressobj(-15).decompress(r)
+            host = sum(len(p) for p in pieces[:64]) / (time.perf_counter() - t0)
+            reps = 4
+            src = b"".join(raws)
+            table = np.zeros(len(raws) * reps, dtype=[("src_offset", "<u8"), ("dst_offset", "<u8"),
+                                                      ("src_length", "<u4"), ("dst_capacity", "<u4")])
+            k = 0
+            for rep in range(reps):
+                at = 0
+                for r in raws:
+                    table[k] = (rep * len(src) + at, k * block, len(r), block)
+                    at += len(r)
+                    k += 1
+            d_src = torch.from_numpy(np.frombuffer(src, dtype=np.uint8).copy()).cuda().repeat(reps)
+            d_dst = torch.zeros(len(table) * block, dtype=torch.uint8, device="cuda")
+            sizes = np.zeros(len(table), dtype=np.uint32)
+            dt = timed(ctx, lambda: check(lib.orcd_inflate_chunks(
+                ctx.handle, d_src.data_ptr(), d_src.numel(), table.ctypes.data, len(table), d_dst.data_ptr(),
+                d_dst.numel(), sizes.ctypes.data, N.IN_DEVICE | N.OUT_DEVICE), ctx.handle))
+            want = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+            total = int(sizes.sum())
+            assert total == len(data) * reps
+            for rep in range(reps):
+                assert torch.equal(d_dst[rep * len(data):(rep + 1) * len(data)], want)
+            print("inflate %s: block %d KiB, %d chunks, %.1f MB deflate -> %.1f MB: %.3f ms, %.1f GB/s decompressed "
+                  "(zlib on one host core: %.2f GB/s)" % (name, block >> 10, len(table), d_src.numel() / 1e6, total / 1e6,
+                                                           dt * 1e3, total / dt / 1e9, host / 1e9), flush=True)
 
 
 if __name__ == "__main__":

@@ -5,10 +5,12 @@
 // flate2 one at a time) that decompresses to at most the file's compression block size.  A stripe
 // holds hundreds to thousands of them, independent of each other: one wavefront inflates one chunk.
 //
-// Inside a chunk deflate is serial -- a symbol's position in the bit stream is known only when the
-// symbol before it has been decoded -- so the wavefront decodes symbols as one (every lane holds the
-// same bit buffer) and uses its lanes where there is something to share out: building the Huffman
-// tables of a block, copying a match, writing finished output to memory.  What the wavefront keeps
+// Inside a chunk deflate is serial -- a token's position in the bit stream is known only when the
+// token before it has been decoded -- so the wavefront works as one and uses its lanes where there
+// is something to share out: lane l decodes the token that would start l bits ahead (one round of
+// table looks for 64 candidates, of which the chain of real tokens is then followed through
+// registers), the lanes build the Huffman tables of a block, copy a match, write finished output
+// to memory.  What the wavefront keeps
 // in LDS: the last 32 KiB of output (all a match may refer to), a tile of the compressed bytes, and
 // per code a table that resolves codes of up to 10 bits in one look (longer ones, which are rare
 // by construction, take the canonical walk over the per-length counts).
@@ -215,6 +217,29 @@ __global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__res
         flushed = upto;
     };
 
+    // A match: `len` bytes that repeat what lies `dist` bytes back.  Every source byte was there
+    // before the match began: of a match that overlaps itself, byte i repeats byte i mod dist.
+    auto copy_match = [&](uint32_t at, uint32_t len, uint32_t dist) -> bool {  // (room for it: checked by the caller)
+        if (dist > at) return false;
+        lds_fence();
+        if (dist >= len) {
+            for (uint32_t i = lane; i < len; i += 64)
+                lds.window[(at + i) & (INF_WIN - 1)] = lds.window[(at - dist + i) & (INF_WIN - 1)];
+        } else {
+            const float inv = 1.0f / (float)dist;  // (i, dist < 512: the quotient is off by one at most)
+            for (uint32_t i = lane; i < len; i += 64) {
+                int32_t r = (int32_t)i - (int32_t)((uint32_t)((float)i * inv) * dist);
+                if (r < 0) r += (int32_t)dist;
+                if (r >= (int32_t)dist) r -= (int32_t)dist;
+                lds.window[(at + i) & (INF_WIN - 1)] = lds.window[(at - dist + (uint32_t)r) & (INF_WIN - 1)];
+            }
+        }
+        lds_fence();
+        return true;
+    };
+    const uintptr_t base16 = in_addr & ~(uintptr_t)15;            // bit 0 of the chunk is bit skew_bits from here
+    const uint32_t skew_bits = (uint32_t)(in_addr & 15) * 8;
+
     const uint32_t clen_slot = CLEN_ORDER[lane < 19 ? lane : 0];  // where lane i puts the i-th code-length length
     bool ok = true, last = false;
     seek(0);
@@ -328,7 +353,88 @@ __global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__res
             }
         }
         // ---- the block's symbols ----
-        for (;;) {
+        // Sixty-four at a time where that works: lane l decodes the token -- a literal, the end
+        // of the block, or a length with its distance -- that would start l bits from here (two
+        // table looks for all lanes together instead of two for every token), then the wavefront
+        // follows the chain of tokens that really are there: the first starts at bit 0, the next
+        // where it ends.  A lane whose bits start no short code, or nothing valid, says so; when
+        // the chain arrives at such a place the one-token-at-a-time reader takes a look, and
+        // reports what is wrong if something is.
+        uint32_t bitpos = (uint32_t)consumed();
+        bool eob = false;
+        while (ok && !eob) {
+            const uint32_t abit0 = skew_bits + bitpos;
+            {
+                const uintptr_t lo = base16 + 4 * (uintptr_t)(abit0 >> 5);
+                if (!tile_ok || lo < tile_at || lo + 24 > tile_at + INF_IN) tile_fill(lo);
+            }
+            const uint32_t tile_off = (uint32_t)(tile_at - base16);
+            uint32_t packed = 0;  // bits of the token | kind << 6 | literal or length << 8 | distance - 1 << 17
+            {
+                const uint32_t ab = abit0 + lane;
+                const uint32_t *wp = (const uint32_t *)(lds.in + (4 * (ab >> 5) - tile_off));
+                const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], sh = ab & 31;
+                uint64_t view = (((uint64_t)w1 << 32) | w0) >> sh;
+                if (sh) view |= (uint64_t)w2 << (64 - sh);
+                const uint32_t e = lds.lit.fast[(uint32_t)view & ((1u << INF_FAST) - 1)];
+                uint32_t used = e & 15;
+                const uint32_t sym = e >> 4;
+                if (e && sym < 256) {
+                    packed = used | (sym << 8);
+                } else if (e && sym == 256) {
+                    packed = used | (1u << 6);
+                } else if (e && sym < 286) {
+                    uint32_t len, dist, extra;
+                    length_code(sym - 257, len, extra);
+                    len += (uint32_t)(view >> used) & ((1u << extra) - 1);
+                    used += extra;
+                    const uint32_t d = lds.dist.fast[(uint32_t)(view >> used) & ((1u << INF_FAST) - 1)];
+                    if (d && (d >> 4) < 30) {
+                        used += d & 15;
+                        distance_code(d >> 4, dist, extra);
+                        dist += (uint32_t)(view >> used) & ((1u << extra) - 1);
+                        used += extra;  // at most 15 + 5 + 15 + 13 bits
+                        packed = used | (2u << 6) | (len << 8) | ((dist - 1) << 17);
+                    }
+                }
+            }
+            uint32_t s = 0;
+            while (s < 64) {
+                const uint32_t tok = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)s);
+                const uint32_t tb = tok & 63, kind = (tok >> 6) & 3;
+                if (tb == 0) break;
+                if (kind == 0) {
+                    if (wpos >= cap) {
+                        ok = false;
+                        break;
+                    }
+                    if (lane == 0) lds.window[wpos & (INF_WIN - 1)] = (uint8_t)(tok >> 8);
+                    wpos++;
+                } else if (kind == 1) {
+                    s += tb;
+                    eob = true;
+                    break;
+                } else {
+                    const uint32_t len = (tok >> 8) & 0x1FF;
+                    if (len > cap - wpos || !copy_match(wpos, len, (tok >> 17) + 1)) {
+                        ok = false;
+                        break;
+                    }
+                    wpos += len;
+                }
+                s += tb;
+                if (wpos - flushed >= INF_FLUSH) flush(wpos);
+            }
+            if (!ok) break;
+            bitpos += s;
+            if ((int64_t)bitpos > limit) {
+                ok = false;
+                break;
+            }
+            if (eob || s) continue;
+            // the token at bitpos is none the lanes could make out: one at a time
+            seek((uint64_t)(bitpos >> 3));
+            take(bitpos & 7);
             refill();
             uint32_t used;
             const uint32_t sym = decode_symbol(lds.lit, buf, used);
@@ -345,7 +451,7 @@ __global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__res
                 if (lane == 0) lds.window[wpos & (INF_WIN - 1)] = (uint8_t)sym;
                 wpos++;
             } else if (sym == 256) {
-                break;
+                eob = true;
             } else {
                 if (sym >= 286) {
                     ok = false;
@@ -363,35 +469,22 @@ __global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__res
                 take(used);
                 distance_code(dsym, dist, extra);
                 dist += take(extra);
-                if (dist > wpos || len > cap - wpos) {
+                if (len > cap - wpos || !copy_match(wpos, len, dist)) {
                     ok = false;
                     break;
                 }
-                lds_fence();
-                // every source byte was there before the match began: of a match that overlaps
-                // itself, byte i repeats byte i mod dist
-                if (dist >= len) {
-                    for (uint32_t i = lane; i < len; i += 64)
-                        lds.window[(wpos + i) & (INF_WIN - 1)] = lds.window[(wpos - dist + i) & (INF_WIN - 1)];
-                } else {
-                    const float inv = 1.0f / (float)dist;  // (i, dist < 512: the quotient is off by one at most)
-                    for (uint32_t i = lane; i < len; i += 64) {
-                        int32_t r = (int32_t)i - (int32_t)((uint32_t)((float)i * inv) * dist);
-                        if (r < 0) r += (int32_t)dist;
-                        if (r >= (int32_t)dist) r -= (int32_t)dist;
-                        lds.window[(wpos + i) & (INF_WIN - 1)] = lds.window[(wpos - dist + (uint32_t)r) & (INF_WIN - 1)];
-                    }
-                }
-                lds_fence();
                 wpos += len;
             }
             if (consumed() > limit) {
                 ok = false;
                 break;
             }
+            bitpos = (uint32_t)consumed();
             if (wpos - flushed >= INF_FLUSH) flush(wpos);
         }
-        if (consumed() > limit) ok = false;
+        if (!ok) break;
+        seek((uint64_t)(bitpos >> 3));  // the next block's header, one field at a time
+        take(bitpos & 7);
     }
     if (ok) flush(wpos);
     if (lane == 0) sizes[chunk] = ok ? wpos : 0xFFFFFFFFu;

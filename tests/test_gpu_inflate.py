@@ -135,6 +135,26 @@ def test_damaged_chunks_are_refused_exactly_when_zlib_refuses_them(ctx):
     assert ok > 5 and bad > 50
 
 
+def test_distances_that_reach_the_far_end_of_the_window(ctx):
+    """Matches 32 KiB back with literals right behind them: the ring that holds the window wraps
+    onto the bytes such a match reads."""
+    rng = np.random.default_rng(4)
+    raws, want = [], []
+    for gap in (32768, 32767, 32760, 32700, 32512, 32768 - 258):
+        head = bytes(rng.integers(0, 256, size=400, dtype=np.uint8))
+        filler = bytes(rng.integers(0, 256, size=gap - 400, dtype=np.uint8))
+        body = bytearray(head + filler)
+        for k in range(40):      # pieces of the head again, a fresh byte or two between them
+            body += head[k * 9:k * 9 + 3 + k % 7] + bytes(rng.integers(0, 256, size=1 + k % 3, dtype=np.uint8))
+        data = bytes(body) * 2
+        raws.append(deflate(data, 9))
+        want.append(data)
+    cap = max(len(w) for w in want)
+    rc, got = run(ctx, raws, cap)
+    assert rc == 0
+    assert got == want
+
+
 def test_many_chunks_in_one_call(ctx):
     rng = np.random.default_rng(3)
     block = 1 << 16
