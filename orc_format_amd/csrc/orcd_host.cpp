@@ -341,6 +341,7 @@ int inflate_one(const uint8_t *src, size_t len, uint64_t block, std::vector<uint
         if (zrc == Z_OK && zs.avail_in == 0 && zs.avail_out != 0) break;  // ends before the stream does
     }
     inflateEnd(&zs);
+    if (out.size() - chunk_at > block) return ORCD_DECOMPRESSION;  // (the last call may have filled the one byte too many)
     return zrc == Z_STREAM_END ? ORCD_OK : ORCD_DECOMPRESSION;
 }
 

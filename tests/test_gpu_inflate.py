@@ -163,3 +163,68 @@ def test_many_chunks_in_one_call(ctx):
     raws = [deflate(p) for p in pieces]
     rc, got = run(ctx, raws, block)
     assert rc == 0 and got == pieces
+
+
+def test_damaged_zlib_files_decode_alike_on_both_paths(tmp_path, monkeypatch):
+    """Bytes of a zlib file's stripes damaged at random: the stripe decode with the chunks inflated
+    on the GPU ends as the one with the host's zlib does -- the same status, and the same arrays
+    when there are any."""
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    from orc_format_amd import Context, read
+    from orc_format_amd.error import OrcError
+    rng = np.random.default_rng(11)
+    rows = 30_000
+    table = pa.table({
+        "a": pa.array(np.cumsum(rng.integers(-5, 9, size=rows))),
+        "b": pa.array(rng.integers(-2**45, 2**45, size=rows), mask=rng.random(rows) < 0.2),
+        "s": pa.array(["w%d" % k for k in rng.integers(0, 500, size=rows)]),
+        "d": pa.array(rng.standard_normal(rows)),
+    })
+    path = str(tmp_path / "z.orc")
+    orc.write_table(table, path, compression="zlib", compression_block_size=65536, stripe_size=1 << 20)
+    image = bytearray(open(path, "rb").read())
+    md0 = read.read_metadata(path)
+    first, last = int(md0.stripes[0].offset), int(md0.stripes[-1].offset)
+    del md0
+
+    def decode(blob, where):
+        if where == "host":
+            monkeypatch.setenv("ORCD_GPU_INFLATE", "0")
+        else:
+            monkeypatch.delenv("ORCD_GPU_INFLATE", raising=False)
+            monkeypatch.setenv("ORCD_GPU_INFLATE_MIN_CHUNKS", "1")
+        out = []
+        try:
+            md = read.read_metadata(blob)
+        except OrcError as e:
+            return [("open", e.code)]
+        with Context(0) as ctx:
+            for si in range(len(md.stripes)):
+                try:
+                    footer = read.read_stripe_footer(md, si)
+                    cols = ctx.decode_stripe(md, si, footer, [1, 2, 3, 4])
+                except OrcError as e:
+                    out.append((si, e.code))
+                    continue
+                out.append((si, 0, [{k: (v.tobytes() if hasattr(v, "tobytes") else v) for k, v in c.items()}
+                                    for c in cols]))
+        return out
+
+    same_ok = same_bad = 0
+    for trial in range(24):
+        blob = bytearray(image)
+        for _ in range(int(rng.integers(1, 4))):
+            at = int(rng.integers(first, max(first + 1, last + 20_000)))
+            if at < len(blob):
+                blob[at] ^= 1 << int(rng.integers(0, 8))
+        a, b = decode(bytes(blob), "host"), decode(bytes(blob), "device")
+        assert len(a) == len(b), trial
+        for x, y in zip(a, b):
+            assert x[:2] == y[:2], (trial, x[:2], y[:2])
+            if x[1] == 0 and x[0] != "open":
+                assert x[2] == y[2], (trial, x[0])
+                same_ok += 1
+            else:
+                same_bad += 1
+    assert same_ok > 5 and same_bad > 5

@@ -248,6 +248,27 @@ def test_entry_points_are_run_starts(oracle, golden_dir, name):
     assert checked > 8
 
 
+def _chunks_of(orc_file, stripe, column, kind):
+    """(header offset, compressed length, stored as it is, decompressed size) of every chunk of a
+    stream of a zlib file."""
+    import zlib
+    streams, _ = orc_file.stripe_footer(stripe)
+    out = []
+    for st in streams:
+        if st.column != column or st.kind != kind:
+            continue
+        buf = orc_file.bytes[st.offset:st.offset + st.length]
+        pos = 0
+        while pos < len(buf):
+            h = buf[pos] | (buf[pos + 1] << 8) | (buf[pos + 2] << 16)
+            n = h >> 1
+            chunk = bytes(buf[pos + 3:pos + 3 + n])
+            size = n if h & 1 else len(zlib.decompressobj(-15).decompress(chunk))
+            out.append((pos, n, bool(h & 1), size))
+            pos += 3 + n
+    return out
+
+
 def test_compression_chunks(tmp_path):
     """Chunk framing by hand (decompress/mod.rs:9-17, 154-176): chunks that end inside values,
     chunks stored as they are, a stream of many chunks -- through a file written by
@@ -279,6 +300,29 @@ def test_compression_chunks(tmp_path):
         read.read_stripe_column(md2, 0, read.read_stripe_footer(md2, 0), 1)
     assert e.value.variant == "Decompression"
     _ = (zlib, rng)
+
+
+def test_a_chunk_one_byte_larger_than_the_compression_block_size(tmp_path):
+    """The PostScript's compressionBlockSize is the most a chunk may decompress to: a file whose
+    chunks hold exactly that much reads, the same file claiming one byte less does not."""
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    path = str(tmp_path / "full.orc")
+    orc.write_table(pa.table({"a": pa.array(np.arange(400_000) % 7919 * 1_000_003)}), path, compression="zlib",
+                    compression_block_size=65536)
+    image = bytearray(open(path, "rb").read())
+    ref = op.OrcFile(path)
+    assert any(not orig and size == 65536 for _, _, orig, size in _chunks_of(ref, 0, 1, op.DATA))
+    md = read.read_metadata(bytes(image))
+    read.read_stripe_column(md, 0, read.read_stripe_footer(md, 0), 1)
+    ps = len(image) - 1 - image[-1]
+    at = bytes(image).find(b"\x18\x80\x80\x04", ps)   # PostScript.compressionBlockSize = 65536
+    assert at >= 0
+    image[at + 1:at + 4] = b"\xff\xff\x03"             # ... = 65535
+    md = read.read_metadata(bytes(image))
+    with pytest.raises(OrcError) as e:
+        read.read_stripe_column(md, 0, read.read_stripe_footer(md, 0), 1)
+    assert e.value.variant == "Decompression"
 
 
 def test_compression_chunks_inflated_by_several_threads(tmp_path, monkeypatch):
