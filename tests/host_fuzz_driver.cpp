@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "orcd.h"
+#include "../orc_format_amd/csrc/orcd_column_internal.h"
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint64_t rnd() {
@@ -53,6 +54,51 @@ static int walk(const std::vector<uint8_t> &image) {
                     checksum += entries[0] + entries[n_entries - 1];
             }
             orcd_column_free(col);
+            // the way of the column calls through a compressed file: the region as it is with its
+            // chunk table, then either the host's inflate or sizes reported from elsewhere (here:
+            // every chunk claims a size of its own making) and the entry points on top of them
+            for (int way = 0; way < 2 && orcd_file_compression(f) != 0; way++) {
+                orcd_column *raw = nullptr;
+                if (orcd_internal_read_column_raw(f, stripe, ft, column, &raw) != ORCD_OK) break;
+                const uint8_t *bytes;
+                size_t len, n_chunks, n_streams;
+                const orcd_internal_chunk *chunks;
+                if (orcd_internal_column_raw(raw, &bytes, &len, &chunks, &n_chunks, &n_streams) != ORCD_OK) return 98;
+                for (size_t j = 0; j < n_chunks; j++) {
+                    if (chunks[j].stream >= n_streams || chunks[j].at > len || chunks[j].len > len - chunks[j].at) return 97;
+                    if (chunks[j].len) checksum += bytes[chunks[j].at] + bytes[chunks[j].at + chunks[j].len - 1];
+                }
+                if (way == 0) {
+                    if (orcd_internal_column_inflate_host(f, raw) == ORCD_OK) {
+                        uint64_t off, n;
+                        for (int k = 0; k < 8; k++)
+                            if (orcd_internal_column_plain_range(raw, k, &off, &n) == ORCD_OK) checksum += off + n;
+                    }
+                } else {
+                    std::vector<uint64_t> plain_off(n_streams, 0), plain_len(n_streams, 0), chunk_off(n_chunks, 0);
+                    uint64_t at = 0;
+                    for (size_t j = 0; j < n_chunks; j++) {
+                        const uint32_t s = chunks[j].stream;
+                        if (j == 0 || chunks[j - 1].stream != s) plain_off[s] = at;
+                        chunk_off[j] = plain_len[s];
+                        const uint64_t size = chunks[j].original ? chunks[j].len : (uint64_t)chunks[j].len * 3 + (j % 5);
+                        plain_len[s] += size;
+                        at += size;
+                    }
+                    if (orcd_internal_column_set_plain(raw, plain_off.data(), plain_len.data(), chunk_off.data()) != ORCD_OK) return 96;
+                    for (int k = 0; k < 8; k++) {
+                        uint64_t off, n;
+                        if (orcd_internal_column_plain_range(raw, k, &off, &n) == ORCD_OK) checksum += off + n;
+                        const uint64_t *entries;
+                        size_t n_entries;
+                        if (orcd_column_entry_points(f, raw, k, &entries, &n_entries) == ORCD_OK && n_entries) {
+                            checksum += entries[0] + entries[n_entries - 1];
+                            if (orcd_internal_column_plain_range(raw, k, &off, &n) == ORCD_OK && entries[n_entries - 1] > n) return 95;
+                        }
+                    }
+                }
+                orcd_column_free(raw);
+            }
             // the handle without bytes: region, stream places, a positioned read of each place
             orcd_column *bare = nullptr;
             if (orcd_stripe_column_open(f, stripe, ft, column, &bare) != ORCD_OK) continue;
