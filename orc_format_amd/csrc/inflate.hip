@@ -3,17 +3,20 @@
 // Every stream of such a file is a chain of chunks (src/read/decompress/mod.rs:9-17: a 3-byte
 // header, then that many bytes), each a raw deflate stream of its own (mod.rs:60-80 hands them to
 // flate2 one at a time) that decompresses to at most the file's compression block size.  A stripe
-// holds hundreds to thousands of them, independent of each other: one wavefront inflates one chunk.
+// holds hundreds to thousands of them, independent of each other: a workgroup of two wavefronts
+// inflates one chunk.
 //
 // Inside a chunk deflate is serial -- a token's position in the bit stream is known only when the
-// token before it has been decoded -- so the wavefront works as one and uses its lanes where there
-// is something to share out: lane l decodes the token that would start l bits ahead (one round of
-// table looks for 64 candidates, of which the chain of real tokens is then followed through
-// registers), the lanes build the Huffman tables of a block, copy a match, write finished output
-// to memory.  What the wavefront keeps
-// in LDS: the last 32 KiB of output (all a match may refer to), a tile of the compressed bytes, and
-// per code a table that resolves codes of up to 10 bits in one look (longer ones, which are rare
-// by construction, take the canonical walk over the per-length counts).
+// token before it has been decoded -- so each wavefront works as one and uses its lanes where
+// there is something to share out.  The first wavefront turns bits into tokens: lane l decodes
+// the token that would start l bits ahead (one round of table looks for 64 candidates, of which
+// the chain of real tokens is then followed through registers), and the lanes build the Huffman
+// tables of a block.  The second turns tokens into bytes: literals in a row by as many lanes,
+// a match by all of them, finished output to memory.  In LDS: the last 32 KiB of output (all a
+// match may refer to), a tile of the compressed bytes, a ring of tokens between the two, and per
+// code a table that resolves codes of up to 12 (literal/length) or 10 (distance) bits in one look
+// (longer ones, which are rare by construction, take the canonical walk over the per-length
+// counts, one token at a time).
 //
 // The checks are those of zlib's inflate, so that the same chunks are accepted and refused as by
 // the host path: block type 3, stored lengths that do not match, more than 286 / 30 symbols, code
@@ -29,11 +32,13 @@ namespace {
 
 constexpr uint32_t INF_WIN = 32768;   // bytes of output kept (the most a distance can be)
 constexpr uint32_t INF_IN = 1024;     // compressed bytes held at a time
-constexpr uint32_t INF_FAST = 10;     // codes up to this many bits resolve in one look
+constexpr uint32_t LIT_FAST = 12;     // literal/length codes up to this many bits resolve in one look
+constexpr uint32_t DIST_FAST = 10;    // ... and distance (and code-length) codes
 constexpr uint32_t INF_FLUSH = 4096;  // finished output goes to memory in pieces of at least this
 
+template <uint32_t FAST>
 struct HuffTable {
-    uint16_t fast[1u << INF_FAST];  // by the next INF_FAST bits: symbol << 4 | length, 0: longer or no code
+    uint16_t fast[1u << FAST];  // by the next FAST bits: symbol << 4 | length, 0: longer or no code
     uint16_t count[16];             // codes of each length
     uint16_t first_code[16];        // scratch of the build: the first code of each length
     uint16_t first_slot[16];        // ... and where its symbols start in `sorted`
@@ -43,7 +48,8 @@ struct HuffTable {
 struct Lds {
     uint8_t window[INF_WIN];
     uint8_t in[INF_IN];
-    HuffTable lit, dist;
+    HuffTable<LIT_FAST> lit;
+    HuffTable<DIST_FAST> dist;
     uint8_t lens[352];  // code-length code lengths at 0, the block's two length lists from 32 on
 };
 
@@ -82,8 +88,9 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // Builds the decoding tables of one code from lens[0, n_sym) (in LDS).  `one_bit_ok`: an
 // incomplete set is accepted when its longest code has one bit (zlib's rule for the literal/length
 // and distance codes; never for the code-length code).  False: the set is not a prefix code.
-__device__ bool build_table(HuffTable &t, const uint8_t *lens, uint32_t n_sym, bool one_bit_ok, uint32_t lane) {
-    for (uint32_t i = lane; i < (1u << INF_FAST) / 2; i += 64) ((uint32_t *)t.fast)[i] = 0;
+template <uint32_t FAST>
+__device__ bool build_table(HuffTable<FAST> &t, const uint8_t *lens, uint32_t n_sym, bool one_bit_ok, uint32_t lane) {
+    for (uint32_t i = lane; i < (1u << FAST) / 2; i += 64) ((uint32_t *)t.fast)[i] = 0;
     if (lane < 16) {  // lane l counts the codes of l bits
         uint32_t n = 0;
         for (uint32_t s = 0; s < n_sym; s++) n += (lens[s] == lane);
@@ -115,9 +122,9 @@ __device__ bool build_table(HuffTable &t, const uint8_t *lens, uint32_t n_sym, b
         for (uint32_t s = 0; s < n_sym; s++) {
             if (lens[s] != lane) continue;
             t.sorted[at++] = (uint16_t)s;
-            if (lane <= INF_FAST) {  // the code arrives lowest bit first: every index that ends in it, reversed
+            if (lane <= FAST) {  // the code arrives lowest bit first: every index that ends in it, reversed
                 const uint32_t rev = __brev(c) >> (32 - lane);
-                for (uint32_t i = rev; i < (1u << INF_FAST); i += 1u << lane) t.fast[i] = (uint16_t)((s << 4) | lane);
+                for (uint32_t i = rev; i < (1u << FAST); i += 1u << lane) t.fast[i] = (uint16_t)((s << 4) | lane);
             }
             c++;
         }
@@ -127,8 +134,9 @@ __device__ bool build_table(HuffTable &t, const uint8_t *lens, uint32_t n_sym, b
 }
 
 // The symbol the low bits of `bits` start with; `used`: its length, 0 when they start no code.
-__device__ __forceinline__ uint32_t decode_symbol(const HuffTable &t, uint64_t bits, uint32_t &used) {
-    const uint32_t e = uni(t.fast[(uint32_t)bits & ((1u << INF_FAST) - 1)]);
+template <uint32_t FAST>
+__device__ __forceinline__ uint32_t decode_symbol(const HuffTable<FAST> &t, uint64_t bits, uint32_t &used) {
+    const uint32_t e = uni(t.fast[(uint32_t)bits & ((1u << FAST) - 1)]);
     if (e) {
         used = e & 15;
         return e >> 4;
@@ -151,13 +159,36 @@ __device__ __forceinline__ uint32_t decode_symbol(const HuffTable &t, uint64_t b
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__restrict__ src, uint64_t src_total,
+// ---- two wavefronts to a chunk ----------------------------------------------------------------
+// The first turns bits into tokens (the header fields, the tables, the 64 candidates at a time)
+// and puts them into a ring of Q_SLOTS words in LDS; the second takes them out in their order and
+// turns them into bytes (literals in a row by as many lanes at once, matches by all lanes, the
+// window, the flushes).  Either ends the other through `state`; both give up waiting after
+// Q_PATIENCE looks, so that neither can hang whatever the other does.
+constexpr uint32_t Q_SLOTS = 256;
+constexpr uint32_t Q_RUNNING = 0, Q_DONE = 1, Q_FAILED = 2;
+constexpr uint32_t Q_PATIENCE = 1u << 22;
+struct TokenQueue {
+    uint32_t slot[Q_SLOTS];  // a token as the lanes pack it: kind << 6 | literal or length << 8 | distance - 1 << 17
+    uint32_t tail, head;     // tokens put in / taken out so far
+    uint32_t state;
+};
+
+__global__ __launch_bounds__(128) void inflate_chunks_pair_kernel(const uint8_t *__restrict__ src, uint64_t src_total,
                                                             const InflateChunk *__restrict__ chunks, uint32_t n_chunks,
                                                             uint8_t *__restrict__ dst, uint32_t *__restrict__ sizes) {
     __shared__ __align__(16) Lds lds;
-    const uint32_t lane = threadIdx.x;
+    __shared__ TokenQueue q;
+    const uint32_t lane = threadIdx.x & 63;
+    const bool writes = threadIdx.x >= 64;  // the second wavefront: tokens to bytes
     const uint32_t chunk = blockIdx.x;
     if (chunk >= n_chunks) return;
+    if (threadIdx.x == 0) {
+        q.tail = 0;
+        q.head = 0;
+        q.state = Q_RUNNING;
+    }
+    __syncthreads();
     const InflateChunk ck = chunks[chunk];
     const uint32_t src_len = ck.src_len, cap = ck.dst_cap;
     const uintptr_t in_addr = (uintptr_t)src + ck.src_off;          // the chunk's first byte
@@ -237,6 +268,91 @@ __global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__res
         lds_fence();
         return true;
     };
+
+    if (writes) {
+        // ---- the second wavefront: tokens, in their order, to bytes ----
+        uint32_t head = 0;
+        bool fine = true;
+        uint32_t idle = 0;
+        for (;;) {
+            const uint32_t state = __hip_atomic_load(&q.state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t tail = __hip_atomic_load(&q.tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tail == head) {
+                if (state != Q_RUNNING) {
+                    fine = state == Q_DONE;
+                    break;
+                }
+                if (++idle > Q_PATIENCE) {  // (never seen: the other wavefront always ends, and says so)
+                    fine = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            idle = 0;
+            const uint32_t count = tail - head < 64 ? tail - head : 64;
+            const uint32_t tok = lane < count ? q.slot[(head + lane) & (Q_SLOTS - 1)] : 0xFFu;
+            const uint64_t literal = __ballot(lane < count && ((tok >> 6) & 3) == 0);
+            uint32_t k = 0;
+            while (k < count) {
+                const uint64_t rest = ~(literal >> k);
+                uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : 64;  // literals in a row from token k on
+                if (run > count - k) run = count - k;
+                if (run) {
+                    if (run > cap - wpos) {
+                        fine = false;
+                        break;
+                    }
+                    if (lane >= k && lane < k + run) lds.window[(wpos + lane - k) & (INF_WIN - 1)] = (uint8_t)(tok >> 8);
+                    wpos += run;
+                    k += run;
+                } else {
+                    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)k);
+                    const uint32_t len = (t >> 8) & 0x1FF;
+                    if (len > cap - wpos || !copy_match(wpos, len, (t >> 17) + 1)) {
+                        fine = false;
+                        break;
+                    }
+                    wpos += len;
+                    k++;
+                }
+                if (wpos - flushed >= INF_FLUSH) flush(wpos);
+            }
+            if (!fine) break;
+            head += count;
+            __hip_atomic_store(&q.head, head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (!fine) __hip_atomic_store(&q.state, Q_FAILED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (fine) flush(wpos);
+        if (lane == 0) sizes[chunk] = fine ? wpos : 0xFFFFFFFFu;
+        return;
+    }
+
+    // ---- the first wavefront: bits to tokens ----
+    uint32_t tail = 0;
+    // room for `count` tokens (at most 64); false: the other wavefront has given up
+    uint32_t head_seen = 0;  // (the other side's count when last looked at: it only grows)
+    auto room = [&](uint32_t count) -> bool {
+        if (tail + count - head_seen <= Q_SLOTS) return true;
+        for (uint32_t idle = 0;; idle++) {
+            head_seen = __hip_atomic_load(&q.head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tail + count - head_seen <= Q_SLOTS) return true;
+            if (__hip_atomic_load(&q.state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != Q_RUNNING || idle > Q_PATIENCE)
+                return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto publish = [&](uint32_t count) {
+        lds_fence();
+        tail += count;
+        __hip_atomic_store(&q.tail, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto push_one = [&](uint32_t tok) -> bool {
+        if (!room(1)) return false;
+        if (lane == 0) q.slot[tail & (Q_SLOTS - 1)] = tok;
+        publish(1);
+        return true;
+    };
     const uintptr_t base16 = in_addr & ~(uintptr_t)15;            // bit 0 of the chunk is bit skew_bits from here
     const uint32_t skew_bits = (uint32_t)(in_addr & 15) * 8;
 
@@ -256,19 +372,21 @@ __global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__res
             refill();
             const uint32_t len = take(16), nlen = take(16);
             const int64_t at = consumed() / 8;
-            if ((len ^ nlen) != 0xFFFF || consumed() > limit || at + len > (int64_t)src_len || len > cap - wpos) {
+            if ((len ^ nlen) != 0xFFFF || consumed() > limit || at + len > (int64_t)src_len) {
                 ok = false;
                 break;
             }
-            for (uint32_t done = 0; done < len;) {
-                const uint32_t piece = len - done < INF_FLUSH ? len - done : INF_FLUSH;
-                for (uint32_t i = lane; i < piece; i += 64)
-                    lds.window[(wpos + i) & (INF_WIN - 1)] = *(const uint8_t *)(in_addr + at + done + i);
-                lds_fence();
-                wpos += piece;
-                done += piece;
-                if (wpos - flushed >= INF_FLUSH) flush(wpos);
+            for (uint32_t done = 0; done < len && ok; done += 64) {  // as literals, a wavefront's worth at a time
+                const uint32_t piece = len - done < 64 ? len - done : 64;
+                if (!room(piece)) {
+                    ok = false;
+                    break;
+                }
+                if (lane < piece)
+                    q.slot[(tail + lane) & (Q_SLOTS - 1)] = (uint32_t)*(const uint8_t *)(in_addr + at + done + lane) << 8;
+                publish(piece);
             }
+            if (!ok) break;
             seek((uint64_t)(at + len));
             continue;
         }
@@ -374,9 +492,8 @@ __global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__res
                 const uint32_t ab = abit0 + lane;
                 const uint32_t *wp = (const uint32_t *)(lds.in + (4 * (ab >> 5) - tile_off));
                 const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], sh = ab & 31;
-                uint64_t view = (((uint64_t)w1 << 32) | w0) >> sh;
-                if (sh) view |= (uint64_t)w2 << (64 - sh);
-                const uint32_t e = lds.lit.fast[(uint32_t)view & ((1u << INF_FAST) - 1)];
+                const uint64_t view = ((((uint64_t)w1 << 32) | w0) >> sh) | (((uint64_t)w2 << 32) << (32 - sh));
+                const uint32_t e = lds.lit.fast[(uint32_t)view & ((1u << LIT_FAST) - 1)];
                 uint32_t used = e & 15;
                 const uint32_t sym = e >> 4;
                 if (e && sym < 256) {
@@ -388,7 +505,7 @@ __global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__res
                     length_code(sym - 257, len, extra);
                     len += (uint32_t)(view >> used) & ((1u << extra) - 1);
                     used += extra;
-                    const uint32_t d = lds.dist.fast[(uint32_t)(view >> used) & ((1u << INF_FAST) - 1)];
+                    const uint32_t d = lds.dist.fast[(uint32_t)(view >> used) & ((1u << DIST_FAST) - 1)];
                     if (d && (d >> 4) < 30) {
                         used += d & 15;
                         distance_code(d >> 4, dist, extra);
@@ -398,32 +515,28 @@ __global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__res
                     }
                 }
             }
+            uint64_t chain = 0;  // the lanes whose tokens are real, but for the end of the block
             uint32_t s = 0;
             while (s < 64) {
                 const uint32_t tok = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)s);
-                const uint32_t tb = tok & 63, kind = (tok >> 6) & 3;
-                if (tb == 0) break;
-                if (kind == 0) {
-                    if (wpos >= cap) {
-                        ok = false;
-                        break;
-                    }
-                    if (lane == 0) lds.window[wpos & (INF_WIN - 1)] = (uint8_t)(tok >> 8);
-                    wpos++;
-                } else if (kind == 1) {
-                    s += tb;
+                if ((tok & 63) == 0) break;
+                if (((tok >> 6) & 3) == 1) {
+                    s += tok & 63;
                     eob = true;
                     break;
-                } else {
-                    const uint32_t len = (tok >> 8) & 0x1FF;
-                    if (len > cap - wpos || !copy_match(wpos, len, (tok >> 17) + 1)) {
-                        ok = false;
-                        break;
-                    }
-                    wpos += len;
                 }
-                s += tb;
-                if (wpos - flushed >= INF_FLUSH) flush(wpos);
+                chain |= 1ull << s;
+                s += tok & 63;
+            }
+            if (chain) {
+                const uint32_t count = (uint32_t)__popcll(chain);
+                if (!room(count)) {
+                    ok = false;
+                    break;
+                }
+                if ((chain >> lane) & 1)
+                    q.slot[(tail + (uint32_t)__popcll(chain & ((1ull << lane) - 1))) & (Q_SLOTS - 1)] = packed;
+                publish(count);
             }
             if (!ok) break;
             bitpos += s;
@@ -444,12 +557,10 @@ __global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__res
             }
             take(used);
             if (sym < 256) {
-                if (wpos >= cap) {
+                if (!push_one(sym << 8)) {
                     ok = false;
                     break;
                 }
-                if (lane == 0) lds.window[wpos & (INF_WIN - 1)] = (uint8_t)sym;
-                wpos++;
             } else if (sym == 256) {
                 eob = true;
             } else {
@@ -469,31 +580,30 @@ __global__ __launch_bounds__(64) void inflate_chunks_kernel(const uint8_t *__res
                 take(used);
                 distance_code(dsym, dist, extra);
                 dist += take(extra);
-                if (len > cap - wpos || !copy_match(wpos, len, dist)) {
+                if (!push_one((2u << 6) | (len << 8) | ((dist - 1) << 17))) {
                     ok = false;
                     break;
                 }
-                wpos += len;
             }
             if (consumed() > limit) {
                 ok = false;
                 break;
             }
             bitpos = (uint32_t)consumed();
-            if (wpos - flushed >= INF_FLUSH) flush(wpos);
         }
         if (!ok) break;
         seek((uint64_t)(bitpos >> 3));  // the next block's header, one field at a time
         take(bitpos & 7);
     }
-    if (ok) flush(wpos);
-    if (lane == 0) sizes[chunk] = ok ? wpos : 0xFFFFFFFFu;
+    // (the other wavefront writes what the chunk came to, when it has seen this)
+    __hip_atomic_store(&q.state, ok ? Q_DONE : Q_FAILED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+
 
 hipError_t launch_inflate_chunks(hipStream_t st, const uint8_t *src, uint64_t src_total, const InflateChunk *chunks,
                                  uint32_t n_chunks, uint8_t *dst, uint32_t *sizes) {
     if (n_chunks == 0) return hipSuccess;
-    inflate_chunks_kernel<<<n_chunks, 64, 0, st>>>(src, src_total, chunks, n_chunks, dst, sizes);
+    inflate_chunks_pair_kernel<<<n_chunks, 128, 0, st>>>(src, src_total, chunks, n_chunks, dst, sizes);
     return hipGetLastError();
 }
 
