@@ -34,6 +34,30 @@ def decode_all(path, repeat=2):
     return best, len(md.stripes)
 
 
+def decode_all_contexts(path, n_contexts, repeat=2):
+    """The same through decode_file_shard with several contexts on the GPU, a host thread each: one
+    stripe's read and chunk walk overlap another's inflate."""
+    from orc_format_amd import Context, read, shard
+    md = read.read_metadata(path)
+    contexts = [Context(0) for _ in range(n_contexts)]
+
+    def on_stripe(context, stripe, cols):
+        for c in cols:
+            c.free()
+        return None
+    best = 1e9
+    for _ in range(repeat + 1):
+        t0 = time.perf_counter()
+        shard.decode_file_shard(contexts[0], md, 0, 1, columns=[1, 2, 3, 4], row_aligned=False,
+                                extra_contexts=contexts[1:], device=True, on_stripe=on_stripe)
+        for c in contexts:
+            c.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    for c in contexts:
+        c.close()
+    return best
+
+
 def main():
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
     rng = np.random.default_rng(5)
@@ -57,6 +81,15 @@ def main():
                     os.environ["ORCD_GPU_INFLATE"] = "0"
                 dt, stripes = decode_all(path)
                 out[where] = dt
+            os.environ.pop("ORCD_GPU_INFLATE", None)
+            several = {n: decode_all_contexts(path, n) for n in (2, 4)}
+            print("  device inflate, contexts: " + ", ".join("%d: %.3f s (%.2f GB/s of file)" % (n, dt, size / dt / 1e9)
+                                                           for n, dt in several.items()), flush=True)
+            os.environ["ORCD_GPU_INFLATE"] = "0"
+            several = {n: decode_all_contexts(path, n) for n in (2, 4)}
+            os.environ.pop("ORCD_GPU_INFLATE", None)
+            print("  host inflate, contexts: " + ", ".join("%d: %.3f s (%.2f GB/s of file)" % (n, dt, size / dt / 1e9)
+                                                         for n, dt in several.items()), flush=True)
             print("zlib file, block %d KiB: %d rows, %.0f MB on disk, %.0f MB as arrays, %d stripes: host inflate "
                   "%.3f s (%.2f GB/s of file), device inflate %.3f s (%.2f GB/s of file)" % (
                       block >> 10, rows, size / 1e6, plain / 1e6, stripes, out["host"], size / out["host"] / 1e9,
