@@ -2496,7 +2496,7 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
     }
 
     // every chunk gets a place of its own: a deflated one the file's compression block size (the
-    // most it may decompress to), a stored one its length; a stream's chunks lie back to back
+    // most it may decompress to) or what its bytes can grow to at most, a stored one its length; a stream's chunks lie back to back
     uint64_t block = orcd_internal_file_compression_block(file);
     if (block > (1ull << 30)) block = 1ull << 30;  // (whatever the PostScript claims)
     std::vector<orcd_chunk> work;
@@ -2522,9 +2522,11 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
                 w.src_offset = r.at + ch.at;
                 w.dst_offset = plain_total;
                 w.src_length = ch.len;
-                w.dst_capacity = (uint32_t)block;
+                // (deflate grows a stream at most 1032-fold: a few bytes cannot need a whole block,
+                // whatever block size the PostScript claims)
+                w.dst_capacity = (uint32_t)std::min<uint64_t>(block, (uint64_t)ch.len * 1032 + 1024);
                 work.push_back(w);
-                plain_total += block;
+                plain_total += w.dst_capacity;
             }
         }
     }
@@ -2552,7 +2554,8 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
                 const orcd_internal_chunk &ch = r.chunks[j];
                 if (ch.original || !ch.len) continue;
                 const bool last = j + 1 == r.n_chunks || r.chunks[j + 1].stream != ch.stream;
-                if (sizes[w++] != block && !last) gaps = true;
+                if (sizes[w] != work[w].dst_capacity && !last) gaps = true;
+                w++;
             }
         }
     }
