@@ -18,7 +18,7 @@ import pyarrow as pa  # noqa: E402
 import pyarrow.orc as orc  # noqa: E402
 
 
-def decode_all(path, repeat=2):
+def decode_all(path, repeat=2, ahead=False):
     from orc_format_amd import Context, read
     md = read.read_metadata(path)
     footers = [read.read_stripe_footer(md, si) for si in range(len(md.stripes))]
@@ -27,6 +27,8 @@ def decode_all(path, repeat=2):
         for _ in range(repeat + 1):   # (the first pass warms the context's blocks)
             t0 = time.perf_counter()
             for si in range(len(md.stripes)):
+                if ahead and si + 1 < len(md.stripes):
+                    ctx.stripe_prefetch(md, si + 1, footers[si + 1], [1, 2, 3, 4])
                 cols = ctx.decode_stripe(md, si, footers[si], [1, 2, 3, 4], device=True)
                 del cols
             ctx.synchronize()
@@ -81,6 +83,7 @@ def main():
                     os.environ["ORCD_GPU_INFLATE"] = "0"
                 dt, stripes = decode_all(path)
                 out[where] = dt
+            out["ahead"], _ = decode_all(path, ahead=True)
             os.environ.pop("ORCD_GPU_INFLATE", None)
             several = {n: decode_all_contexts(path, n) for n in (2, 4)}
             print("  device inflate, contexts: " + ", ".join("%d: %.3f s (%.2f GB/s of file)" % (n, dt, size / dt / 1e9)
@@ -91,9 +94,10 @@ def main():
             print("  host inflate, contexts: " + ", ".join("%d: %.3f s (%.2f GB/s of file)" % (n, dt, size / dt / 1e9)
                                                          for n, dt in several.items()), flush=True)
             print("zlib file, block %d KiB: %d rows, %.0f MB on disk, %.0f MB as arrays, %d stripes: host inflate "
-                  "%.3f s (%.2f GB/s of file), device inflate %.3f s (%.2f GB/s of file)" % (
+                  "%.3f s (%.2f GB/s of file), device inflate %.3f s (%.2f GB/s of file), "
+                  "with the next stripe read ahead %.3f s (%.2f GB/s)" % (
                       block >> 10, rows, size / 1e6, plain / 1e6, stripes, out["host"], size / out["host"] / 1e9,
-                      out["device"], size / out["device"] / 1e9), flush=True)
+                      out["device"], size / out["device"] / 1e9, out["ahead"], size / out["ahead"] / 1e9), flush=True)
 
 
 if __name__ == "__main__":

@@ -456,8 +456,9 @@ int orcd_decode_stripe(orcd_ctx *ctx, orcd_file *file, size_t stripe,
  * then waits for those bytes instead of reading them; with other arguments it reads for itself and
  * the bytes read ahead stay until they are claimed, pushed out or the context is destroyed.  At
  * most two stripes are kept ahead, served in the order given: a further hint pushes out the oldest
- * one if that has been read and never asked for, and is ignored otherwise; compressed files are
- * not read ahead.  `file` and `footer` must stay open until the stripe has been decoded or the
+ * one if that has been read and never asked for, and is ignored otherwise.  Of compressed files,
+ * zlib ones are read ahead (the bytes wait in host memory too, where the decode call walks the chunk
+ * headers) unless ORCD_GPU_INFLATE=0; the others are not.  `file` and `footer` must stay open until the stripe has been decoded or the
  * context destroyed.  Returns what finding the region returns (ORCD_INVALID_COLUMN, ORCD_OUT_OF_SPEC
  * for a region outside the file, ...); a failed read shows when the stripe is decoded. */
 int orcd_stripe_prefetch(orcd_ctx *ctx, orcd_file *file, size_t stripe,

@@ -208,6 +208,10 @@ struct PrefetchJob {
     size_t stripe = 0;
     uint64_t file_off = 0, len = 0;  // the region of the file
     void *d_buf = nullptr;           // a block of the context's device cache
+    // a compressed file: the bytes stay in host memory as well (the decode call walks the chunk
+    // headers there)
+    bool keep_host = false;
+    std::vector<uint8_t> host;
     int status = ORCD_OK;
     bool done = false;
 };
@@ -2029,8 +2033,20 @@ void prefetch_serve(orcd_ctx *c) {
                     break;
                 }
         }
-        const HostSource region = {job->file, job->file_off, nullptr};
-        int rc = chunked_to_device(c, pf->stage, region, job->len, (uint8_t *)job->d_buf);
+        int rc = ORCD_OK;
+        if (job->keep_host) {
+            try {
+                job->host.resize(job->len);
+                rc = orcd_file_read_at(job->file, job->file_off, job->len, job->host.data());
+            } catch (const std::bad_alloc &) {
+                rc = ORCD_NO_MEMORY;
+            }
+            const HostSource region = {nullptr, 0, job->host.data()};
+            if (rc == ORCD_OK) rc = chunked_to_device(c, pf->stage, region, job->len, (uint8_t *)job->d_buf);
+        } else {
+            const HostSource region = {job->file, job->file_off, nullptr};
+            rc = chunked_to_device(c, pf->stage, region, job->len, (uint8_t *)job->d_buf);
+        }
         // the bytes are on the device when the job is reported done: whoever claims it needs no
         // ordering against this thread's stream
         if (hipStreamSynchronize(pf->stage.stream) != hipSuccess && rc == ORCD_OK) rc = ORCD_HIP_ERROR;
@@ -2082,7 +2098,8 @@ void prefetch_shutdown(orcd_ctx *c) {
 // The device copy of file[file_off, file_off + len) of `stripe`, if it was asked for ahead of
 // time: waits for the read, hands the block over (the caller owns it then) or returns null (never
 // asked for, or the read failed: the caller reads for itself and reports what it finds).
-void *prefetch_claim(orcd_ctx *c, orcd_file *file, size_t stripe, uint64_t file_off, uint64_t len) {
+void *prefetch_claim(orcd_ctx *c, orcd_file *file, size_t stripe, uint64_t file_off, uint64_t len,
+                     std::vector<uint8_t> *host = nullptr) {
     Prefetcher *pf = c->prefetcher;
     if (!pf) return nullptr;
     std::unique_lock<std::mutex> lock(pf->m);
@@ -2093,6 +2110,7 @@ void *prefetch_claim(orcd_ctx *c, orcd_file *file, size_t stripe, uint64_t file_
         pf->jobs.erase(it);
         void *buf = j->d_buf;
         const int rc = j->status;
+        if (host) host->swap(j->host);
         delete j;
         if (rc != ORCD_OK) {
             lock.unlock();
@@ -2451,8 +2469,11 @@ int run_moves(orcd_ctx *c, const std::vector<InflateMove> &moves, const uint8_t 
     return ORCD_OK;
 }
 
+// (ahead_dev / ahead_host: the stripe's bytes as orcd_stripe_prefetch left them, on the device and in
+// host memory -- the columns' regions point into the latter; null: nothing was read ahead)
 int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::unique_ptr<StripeJob>> &jobs,
-                                 size_t n_columns, Pending &stripe_mem) {
+                                 size_t n_columns, Pending &stripe_mem, const uint8_t *ahead_dev = nullptr,
+                                 const uint8_t *ahead_host = nullptr) {
     struct Raw {
         const uint8_t *bytes;
         size_t len, n_chunks, n_streams;
@@ -2466,6 +2487,11 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
         Raw &r = raw[i];
         ORCD_TRY(orcd_internal_column_raw((*jobs[i]).col, &r.bytes, &r.len, &r.chunks, &r.n_chunks, &r.n_streams));
         for (size_t j = 0; j < r.n_chunks; j++) deflated += (!r.chunks[j].original && r.chunks[j].len);
+        if (ahead_dev) {  // where the region lies in the copy made ahead of time
+            r.at = (uint64_t)(r.bytes - ahead_host);
+            raw_total = std::max<uint64_t>(raw_total, r.at + r.len);
+            continue;
+        }
         r.at = raw_total;
         raw_total += (r.len + 255) & ~(uint64_t)255;
     }
@@ -2531,16 +2557,20 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
         }
     }
     Pending hold(c);  // the compressed bytes: done with when the sizes are back
-    ORCD_TRY(dev_alloc(c, std::max<uint64_t>(raw_total, 256), &hold.tmp));
-    ORCD_TRY(dev_alloc(c, std::max<uint64_t>(plain_total, 256), &stripe_mem.tmp));
-    for (size_t i = 0; i < n_columns; i++) {
-        if (!raw[i].len) continue;
-        const HostSource src = {nullptr, 0, raw[i].bytes};
-        ORCD_TRY(chunked_to_device(c, src, raw[i].len, (uint8_t *)hold.tmp + raw[i].at));
+    const uint8_t *d_raw = ahead_dev;
+    if (!d_raw) {
+        ORCD_TRY(dev_alloc(c, std::max<uint64_t>(raw_total, 256), &hold.tmp));
+        d_raw = (const uint8_t *)hold.tmp;
+        for (size_t i = 0; i < n_columns; i++) {
+            if (!raw[i].len) continue;
+            const HostSource src = {nullptr, 0, raw[i].bytes};
+            ORCD_TRY(chunked_to_device(c, src, raw[i].len, (uint8_t *)hold.tmp + raw[i].at));
+        }
     }
-    ORCD_TRY(run_moves(c, stored, (const uint8_t *)hold.tmp, (uint8_t *)stripe_mem.tmp));
+    ORCD_TRY(dev_alloc(c, std::max<uint64_t>(plain_total, 256), &stripe_mem.tmp));
+    ORCD_TRY(run_moves(c, stored, d_raw, (uint8_t *)stripe_mem.tmp));
     std::vector<uint32_t> sizes(work.size());
-    ORCD_TRY(inflate_device(c, (const uint8_t *)hold.tmp, raw_total, work.data(), work.size(), (uint8_t *)stripe_mem.tmp,
+    ORCD_TRY(inflate_device(c, d_raw, raw_total, work.data(), work.size(), (uint8_t *)stripe_mem.tmp,
                             plain_total, sizes.data()));  // (waits for the stream)
 
     // where everything came to lie; a chunk that did not fill its place -- other than a stream's
@@ -2601,16 +2631,35 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     orcd_stripe_info si;
     ORCD_TRY(orcd_file_stripe(file, stripe, &si));
     const bool compressed = orcd_file_compression(file) != 0;
+    // a compressed stripe that was read ahead of time (orcd_stripe_prefetch): its bytes are in host
+    // memory, for the walk over the chunk headers, and on the device, for the inflate
+    std::vector<uint8_t> ahead_host;
+    Pending ahead(c);
+    uint64_t ahead_at = 0, ahead_len = 0;
+    if (compressed && c->prefetcher) {
+        for (size_t i = 0; i < n_columns; i++)
+            if (columns[i] >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
+        if (stripe_columns_region(file, stripe, footer, columns, n_columns, &ahead_at, &ahead_len) == ORCD_OK && ahead_len)
+            ahead.tmp = prefetch_claim(c, file, stripe, ahead_at, ahead_len, &ahead_host);
+        if (ahead.tmp && ahead_host.size() != ahead_len) {  // (not a job of the compressed kind)
+            dev_free(c, ahead.tmp);
+            ahead.tmp = nullptr;
+        }
+    }
     for (size_t i = 0; i < n_columns; i++) {
         if (columns[i] >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
         (*jobs[i]).type_kind = orcd_file_type_kind(file, columns[i]);
         // (a compressed file: the host reads each column's region and finds its compression chunks;
         // they are decompressed below, src/read/decompress/mod.rs:60-80, on the device or the host)
-        if (compressed) ORCD_TRY(orcd_internal_read_column_raw(file, stripe, footer, columns[i], &(*jobs[i]).col));
+        if (compressed)
+            ORCD_TRY(orcd_internal_column_raw_from(file, stripe, footer, columns[i], ahead.tmp ? ahead_host.data() : nullptr,
+                                                   ahead_at, ahead_len, &(*jobs[i]).col));
         else ORCD_TRY(orcd_stripe_column_open(file, stripe, footer, columns[i], &(*jobs[i]).col));
     }
     StripeBytes sb;
-    if (compressed) ORCD_TRY(compressed_columns_to_device(c, file, jobs, n_columns, stripe_mem));
+    if (compressed)
+        ORCD_TRY(compressed_columns_to_device(c, file, jobs, n_columns, stripe_mem, (const uint8_t *)ahead.tmp,
+                                              ahead.tmp ? ahead_host.data() : nullptr));
     sb.lo = ~0ull;
     for (size_t i = 0; i < n_columns && !compressed; i++) {
         uint64_t off = 0, n = 0;
@@ -2762,7 +2811,10 @@ int orcd_decode_column(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
 int orcd_stripe_prefetch(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
                          const uint32_t *columns, size_t n_columns) try {
     if (!c || !file || !footer || (n_columns && !columns)) return ORCD_INVALID_ARGUMENT;
-    if (orcd_file_compression(file) != 0) return ORCD_OK;  // (a compressed stripe is inflated by the decode call)
+    // (a compressed stripe is read ahead when its chunks may be inflated on the device; the host's
+    // inflate reads for itself)
+    const bool compressed = orcd_file_compression(file) != 0;
+    if (compressed && (orcd_file_compression(file) != 1 || gpu_inflate_min_chunks() == ~(size_t)0)) return ORCD_OK;
     uint64_t file_off = 0, len = 0;
     ORCD_TRY(stripe_columns_region(file, stripe, footer, columns, n_columns, &file_off, &len));
     if (len == 0) return ORCD_OK;
@@ -2794,6 +2846,7 @@ int orcd_stripe_prefetch(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd
     job->stripe = stripe;
     job->file_off = file_off;
     job->len = len;
+    job->keep_host = compressed;
     ORCD_TRY(dev_alloc(c, len, &job->d_buf));
     {
         std::lock_guard<std::mutex> lock(pf->m);

@@ -20,6 +20,9 @@ struct orcd_internal_chunk {
 };
 extern "C" int orcd_internal_read_column_raw(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft, uint32_t column,
                                              orcd_column **out);
+extern "C" int orcd_internal_column_raw_from(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft, uint32_t column,
+                                             const uint8_t *region_bytes, uint64_t region_at, uint64_t region_len,
+                                             orcd_column **out);
 extern "C" int orcd_internal_column_raw(const orcd_column *col, const uint8_t **bytes, size_t *len,
                                         const orcd_internal_chunk **chunks, size_t *n_chunks, size_t *n_streams);
 extern "C" int orcd_internal_column_inflate_host(orcd_file *f, orcd_column *col);

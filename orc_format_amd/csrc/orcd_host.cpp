@@ -176,6 +176,11 @@ struct orcd_column {
     bool raw = false;
     std::vector<orcd_internal_chunk> raw_chunks;
     uint32_t raw_streams = 0;
+    // ... or the region lies in memory of the caller's (read ahead of time), not in `data`
+    const uint8_t *ext = nullptr;
+    size_t ext_len = 0;
+    const uint8_t *region() const { return ext ? ext : data.data(); }
+    size_t region_len() const { return ext ? ext_len : data.size(); }
     uint32_t column = 0;
     uint64_t number_of_rows = 0;
     size_t stripe = 0;
@@ -794,8 +799,11 @@ int orcd_stripe_footer_stream(const orcd_stripe_footer *ft, size_t i, orcd_strea
 } ORCD_CATCH
 
 // The column's region read as it is in the file (src/read/mod.rs:129-144).
+// (ext: bytes [ext_at, ext_at + ext_len) of the file that the caller holds already -- the region is
+// taken from there, without a copy, and must lie inside)
 static int read_column_region(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft, uint32_t column,
-                              orcd_column **out) {
+                              orcd_column **out, const uint8_t *ext = nullptr, uint64_t ext_at = 0,
+                              uint64_t ext_len = 0) {
     if (!f || !ft || !out) return ORCD_INVALID_ARGUMENT;
     *out = nullptr;
     if (stripe >= f->stripes.size()) return ORCD_INVALID_ARGUMENT;
@@ -814,7 +822,14 @@ static int read_column_region(orcd_file *f, size_t stripe, const orcd_stripe_foo
     uint64_t region_at;
     if (!add_ok(f->stripes[stripe].offset, start, region_at)) return ORCD_OUT_OF_SPEC;
     std::unique_ptr<orcd_column> col(new orcd_column());
-    if (!f->src.read_at(region_at, length, col->data)) return ORCD_OUT_OF_SPEC;
+    if (ext) {
+        if (region_at < ext_at || region_at - ext_at > ext_len || length > ext_len - (region_at - ext_at))
+            return ORCD_INVALID_ARGUMENT;
+        col->ext = ext + (region_at - ext_at);
+        col->ext_len = (size_t)length;
+    } else if (!f->src.read_at(region_at, length, col->data)) {
+        return ORCD_OUT_OF_SPEC;
+    }
     col->column = column;
     col->number_of_rows = f->stripes[stripe].number_of_rows;
     col->stripe = stripe;
@@ -834,16 +849,18 @@ static int inflate_column(orcd_file *f, orcd_column *col) {
     col->chunks.clear();
     for (const auto &s : col->footer->streams) {
         if (s.column != col->column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
-        if (start2 > col->data.size() || s.length > col->data.size() - start2) return ORCD_OUT_OF_SPEC;
+        if (start2 > col->region_len() || s.length > col->region_len() - start2) return ORCD_OUT_OF_SPEC;
         while (plain.size() & 15) plain.push_back(0);  // streams start 16-byte aligned
         col->plain_off.push_back(plain.size());
         col->chunks.emplace_back();
-        const int rc = inflate_chunks(f->compression, col->data.data() + start2, (size_t)s.length, f->compression_block, plain, &col->chunks.back());
+        const int rc = inflate_chunks(f->compression, col->region() + start2, (size_t)s.length, f->compression_block, plain, &col->chunks.back());
         if (rc != ORCD_OK) return rc;
         col->plain_len.push_back(plain.size() - col->plain_off.back());
         start2 += s.length;
     }
     col->data.swap(plain);
+    col->ext = nullptr;
+    col->ext_len = 0;
     col->compressed = true;
     col->raw = false;
     col->raw_chunks.clear();
@@ -872,9 +889,17 @@ int orcd_read_stripe_column(orcd_file *f, size_t stripe, const orcd_stripe_foote
 // device and report the sizes (orcd_internal_column_set_plain), or leave it to the host
 // (orcd_internal_column_inflate_host).
 int orcd_internal_read_column_raw(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft, uint32_t column,
+                                  orcd_column **out) {
+    return orcd_internal_column_raw_from(f, stripe, ft, column, nullptr, 0, 0, out);
+}
+
+// (region_bytes: file[region_at, region_at + region_len) in the caller's memory, kept by the caller
+// for as long as the handle is raw; null: the column's region is read from the file)
+int orcd_internal_column_raw_from(orcd_file *f, size_t stripe, const orcd_stripe_footer *ft, uint32_t column,
+                                  const uint8_t *region_bytes, uint64_t region_at, uint64_t region_len,
                                   orcd_column **out) try {
     orcd_column *col = nullptr;
-    const int rc = read_column_region(f, stripe, ft, column, &col);
+    const int rc = read_column_region(f, stripe, ft, column, &col, region_bytes, region_at, region_len);
     if (rc != ORCD_OK) return rc;
     std::unique_ptr<orcd_column> hold(col);
     if (f->compression == 0) return ORCD_INVALID_ARGUMENT;
@@ -882,8 +907,8 @@ int orcd_internal_read_column_raw(orcd_file *f, size_t stripe, const orcd_stripe
     uint32_t k = 0;
     for (const auto &s : ft->streams) {
         if (s.column != column || s.kind == ORCD_STREAM_ROW_INDEX) continue;
-        if (start > col->data.size() || s.length > col->data.size() - start) return ORCD_OUT_OF_SPEC;
-        const uint8_t *src = col->data.data() + start;
+        if (start > col->region_len() || s.length > col->region_len() - start) return ORCD_OUT_OF_SPEC;
+        const uint8_t *src = col->region() + start;
         const size_t n = (size_t)s.length;
         for (size_t pos = 0; pos < n;) {  // (the walk of inflate_chunks)
             if (n - pos < 3) return ORCD_DECOMPRESSION;
@@ -912,8 +937,8 @@ int orcd_internal_read_column_raw(orcd_file *f, size_t stripe, const orcd_stripe
 int orcd_internal_column_raw(const orcd_column *col, const uint8_t **bytes, size_t *len,
                              const orcd_internal_chunk **chunks, size_t *n_chunks, size_t *n_streams) {
     if (!col || !col->raw) return ORCD_INVALID_ARGUMENT;
-    *bytes = col->data.data();
-    *len = col->data.size();
+    *bytes = col->region();
+    *len = col->region_len();
     *chunks = col->raw_chunks.data();
     *n_chunks = col->raw_chunks.size();
     *n_streams = col->raw_streams;
@@ -940,6 +965,8 @@ int orcd_internal_column_set_plain(orcd_column *col, const uint64_t *plain_off, 
     col->raw = false;
     col->has_data = false;
     std::vector<uint8_t>().swap(col->data);
+    col->ext = nullptr;
+    col->ext_len = 0;
     std::vector<orcd_internal_chunk>().swap(col->raw_chunks);
     return ORCD_OK;
 } ORCD_CATCH

@@ -169,3 +169,38 @@ def test_every_codec_decodes_to_what_pyarrow_reads(tmp_path, codec):
                 assert (col["values"] == np.array(dense.to_pylist(), dtype=np.int64)).all(), (codec, stripe, name)
         first += n
     assert first == rows
+
+
+def test_a_compressed_stripe_read_ahead_decodes_the_same(tmp_path, inflate_where):
+    """orcd_stripe_prefetch on a zlib file: the stripe's bytes wait in host memory (for the walk over
+    the chunk headers) and on the device (for the inflate); what is decoded is what a decode
+    without the hint gives, whether the hint was for these columns, for others, or never used."""
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    from orc_format_amd import Context, read
+    rng = np.random.default_rng(17)
+    rows = 120_000
+    table = pa.table({
+        "a": pa.array(np.cumsum(rng.integers(-5, 9, size=rows))),
+        "s": pa.array(["w%d" % k for k in rng.integers(0, 5000, size=rows)], mask=rng.random(rows) < 0.1),
+        "d": pa.array(rng.standard_normal(rows)),
+    })
+    path = str(tmp_path / "ahead.orc")
+    orc.write_table(table, path, compression="zlib", compression_block_size=65536, stripe_size=1 << 19)
+    md = read.read_metadata(path)
+    n = len(md.stripes)
+    footers = [read.read_stripe_footer(md, si) for si in range(n)]
+
+    def plain(cols):
+        return [{k: (v.tobytes() if hasattr(v, "tobytes") else v) for k, v in c.items()} for c in cols]
+    with Context(0) as ctx:
+        want = [plain(ctx.decode_stripe(md, si, footers[si], [1, 2, 3])) for si in range(n)]
+    with Context(0) as ctx:
+        for si in range(n):
+            if si + 1 < n:
+                ctx.stripe_prefetch(md, si + 1, footers[si + 1], [1, 2, 3])
+            assert plain(ctx.decode_stripe(md, si, footers[si], [1, 2, 3])) == want[si], si
+        # a hint for other columns than are decoded, and one that is never used
+        ctx.stripe_prefetch(md, 0, footers[0], [1, 3])
+        assert plain(ctx.decode_stripe(md, 0, footers[0], [1, 2, 3])) == want[0]
+        ctx.stripe_prefetch(md, n - 1, footers[n - 1], [2])
