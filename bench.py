@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=None,
                     help="values per GPU per step (default 1e9; 2.5e8 strings for strings_w6)")
-    ap.add_argument("--workload", default="direct_w17", choices=sorted(WORKLOADS) + ["strings_file"])
+    ap.add_argument("--workload", default="direct_w17", choices=sorted(WORKLOADS) + ["strings_file", "zlib_file"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the `workloads` object (the other configurations, shorter runs)")
@@ -152,6 +152,10 @@ def main():
 
 
 def run_workload(args, workload, rank, world, local_rank, dist, torch, np):
+    if workload == "zlib_file":
+        args = argparse.Namespace(**vars(args))
+        args.workload = workload
+        return bench_zlib_file(args, rank, world, local_rank, dist, torch, np)
     if workload == "strings_file":
         args = argparse.Namespace(**vars(args))
         args.workload = workload
@@ -484,6 +488,93 @@ def bench_strings_file(args, rank, world, local_rank, dist, torch, np):
                                "U[8,56] as RLE v2 Direct width 6, ASCII DATA (seed 46), %d bytes per GPU; "
                                "%d contexts per GPU%s" % (n_stripes, FILE_STRINGS_PER_STRIPE, size, FILE_CONTEXTS,
                                                           ", each reading its next stripe ahead" if FILE_PREFETCH else ""),
+                   "file_bytes_per_gpu": size, "stripes": n_stripes,
+                   "parallelism": "stripe-sharded x%d" % world},
+    }
+
+
+def bench_zlib_file(args, rank, world, local_rank, dist, torch, np):
+    """One step = one pass over this rank's zlib-compressed ORC file (pyarrow's writer, 64 KiB
+    compression blocks; four columns: slowly varying and random 64-bit integers, doubles, short
+    strings): stripe reads, the chunks inflated on the GPU (by the host's zlib threads with
+    ORCD_GPU_INFLATE=0), the streams decoded, the columns left on the device.  Like strings_file it
+    measures a whole path and carries no roofline; not part of the default run (writing the file
+    takes the host half a minute)."""
+    import shutil
+    import tempfile
+    import pyarrow as pa
+    import pyarrow.orc as orc
+    from orc_format_amd import Context, read, shard
+
+    rows = args.rows or 20_000_000
+    rng = np.random.default_rng(5 + 1000 * rank)
+    table = pa.table({
+        "walk": pa.array(np.cumsum(rng.integers(-50, 51, size=rows))),
+        "wide": pa.array(rng.integers(0, 2**40, size=rows)),
+        "real": pa.array(np.round(rng.standard_normal(rows), 3)),
+        "word": pa.array(np.char.add("k", rng.integers(0, 10**6, size=rows).astype(str))),
+    })
+    tmp = tempfile.mkdtemp(prefix="orcd_bench_")
+    try:
+        path = os.path.join(tmp, "zlib_%d.orc" % rank)
+        orc.write_table(table, path, compression="zlib", compression_block_size=65536, stripe_size=64 << 20,
+                        dictionary_key_size_threshold=0.0)
+        size = os.path.getsize(path)
+        md = read.read_metadata(path)
+        n_stripes = len(md.stripes)
+        contexts = [Context(local_rank) for _ in range(FILE_CONTEXTS)]
+        # the first stripe against what was written
+        first = contexts[0].decode_stripe(md, 0, read.read_stripe_footer(md, 0), [1, 2, 3])
+        n0 = first[0]["values"].size
+        for k, name in enumerate(["walk", "wide", "real"]):
+            if not np.array_equal(first[k]["values"], table.column(name).to_numpy()[:n0]):
+                raise SystemExit("bench.py: column %s of the first stripe differs from what was written" % name)
+        decoded = [0]
+
+        def on_stripe(context, stripe, cols):
+            for c in cols:
+                decoded[0] += c.num_slots * 8 + c.num_bytes
+                c.free()
+            return None
+
+        def one_pass():
+            return shard.decode_file_shard(contexts[0], md, 0, 1, columns=[1, 2, 3, 4], row_aligned=False,
+                                           extra_contexts=contexts[1:], device=True, on_stripe=on_stripe,
+                                           prefetch=FILE_PREFETCH)
+
+        def barrier():
+            for c in contexts:
+                c.synchronize()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+
+        for _ in range(min(args.warmup, 1)):
+            one_pass()
+        steps = max(1, min(args.steps, 5))
+        decoded[0] = 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_pass()
+        barrier()
+        elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist, device=REDUCE_DEVICE)
+        for c in contexts:
+            c.close()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    where = "the host's zlib threads" if os.environ.get("ORCD_GPU_INFLATE", "")[:1] == "0" else "the GPU"
+    return {
+        "metric": "end-to-end GB/s of zlib ORC file (read + H2D + inflate + decode)",
+        "value": round(size * steps * world / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": world,
+        "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": round(elapsed / steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "decoded_GBps": round(decoded[0] * world / elapsed / 1e9, 2),
+        "config": {"workload": "zlib_file: pyarrow-written ORC file, zlib, 64 KiB compression blocks, %d rows x 4 "
+                               "columns (seed 5), %d bytes and %d stripes per GPU; chunks inflated by %s; %d contexts "
+                               "per GPU%s" % (rows, size, n_stripes, where, FILE_CONTEXTS,
+                                              ", each reading its next stripe ahead" if FILE_PREFETCH else ""),
                    "file_bytes_per_gpu": size, "stripes": n_stripes,
                    "parallelism": "stripe-sharded x%d" % world},
     }
