@@ -2440,11 +2440,12 @@ struct StreamBatch {
 };
 
 // ---- the columns of a compressed stripe, decompressed, on the device ----------------------------
-// Zlib chunks are inflated by the GPU when the stripe's columns hold enough of them to fill it (a
-// wavefront inflates a chunk at a few megabytes a second; what pays is thousands at once); fewer
-// chunks, and the other codecs, are decompressed by the host's threads and copied over.
-// ORCD_GPU_INFLATE=0 keeps everything on the host, ORCD_GPU_INFLATE_MIN_CHUNKS moves the limit.
-constexpr size_t GPU_INFLATE_MIN_CHUNKS = 1024;
+// Zlib chunks are inflated by the GPU (a workgroup inflates a chunk at a few megabytes a second;
+// what pays is hundreds at once) and, the largest of them, by the host's threads at the same time
+// (split_for_host); a stripe of only a few chunks, and the other codecs, are decompressed by the
+// host's threads alone and copied over.  ORCD_GPU_INFLATE=0 keeps everything on the host,
+// ORCD_GPU_INFLATE_MIN_CHUNKS moves the limit.
+constexpr size_t GPU_INFLATE_MIN_CHUNKS = 64;
 constexpr uint64_t MOVE_PIECE = 16384;  // bytes one workgroup of the move kernel copies
 
 size_t gpu_inflate_min_chunks() {
@@ -2453,6 +2454,44 @@ size_t gpu_inflate_min_chunks() {
     if (const char *e = getenv("ORCD_GPU_INFLATE_MIN_CHUNKS"))
         if (*e) return (size_t)strtoull(e, nullptr, 10);
     return GPU_INFLATE_MIN_CHUNKS;
+}
+
+// The GPU inflates a chunk in a time that goes with its compressed size, however few chunks there
+// are, while the host's threads share theirs out: when the chunks do not fill the chip, the largest
+// are better off on the host, at the same time.  to_host[k]: chunk k of `work` is the host's.
+// Rates as measured on an MI355X and its host: 0.165 microseconds per compressed byte for a lone
+// chunk on the GPU, INFLATE_PLACES chunks at a time; 0.4 GB/s decompressed per host thread.
+// ORCD_GPU_INFLATE_SPLIT=0: everything to the GPU; =2: every other chunk to the host (tests).
+constexpr double GPU_US_PER_BYTE = 0.165, HOST_US_PER_BYTE = 1.0 / 400.0;
+constexpr size_t INFLATE_PLACES = 768;
+
+std::vector<char> split_for_host(const std::vector<orcd_chunk> &work) {
+    std::vector<char> to_host(work.size(), 0);
+    int mode = 1;
+    if (const char *e = getenv("ORCD_GPU_INFLATE_SPLIT"))
+        if (*e) mode = atoi(e);
+    if (mode == 0) return to_host;
+    if (mode == 2) {
+        for (size_t k = 1; k < work.size(); k += 2) to_host[k] = 1;
+        return to_host;
+    }
+    std::vector<size_t> order(work.size());
+    for (size_t k = 0; k < order.size(); k++) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return work[a].src_length > work[b].src_length; });
+    const unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    double gpu_bytes = 0, host_us = 0;
+    for (const orcd_chunk &w : work) gpu_bytes += w.src_length;
+    // largest first: the host takes a chunk as long as it still ends before the GPU would
+    for (size_t i = 0; i < order.size(); i++) {
+        const orcd_chunk &w = work[order[i]];
+        const double gpu_us = std::max<double>(w.src_length, gpu_bytes / INFLATE_PLACES) * GPU_US_PER_BYTE;
+        const double host_next = host_us + (double)w.dst_capacity * HOST_US_PER_BYTE / threads;
+        if (host_next >= gpu_us) break;
+        to_host[order[i]] = 1;
+        host_us = host_next;
+        gpu_bytes -= w.src_length;
+    }
+    return to_host;
 }
 
 void add_move(std::vector<InflateMove> &moves, uint64_t from, uint64_t to, uint64_t len) {
@@ -2526,6 +2565,7 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
     uint64_t block = orcd_internal_file_compression_block(file);
     if (block > (1ull << 30)) block = 1ull << 30;  // (whatever the PostScript claims)
     std::vector<orcd_chunk> work;
+    std::vector<const uint8_t *> work_host;  // the same chunks in host memory
     std::vector<InflateMove> stored;
     std::vector<std::vector<uint64_t>> place(n_columns);
     uint64_t plain_total = 0;
@@ -2552,6 +2592,7 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
                 // whatever block size the PostScript claims)
                 w.dst_capacity = (uint32_t)std::min<uint64_t>(block, (uint64_t)ch.len * 1032 + 1024);
                 work.push_back(w);
+                work_host.push_back(r.bytes + ch.at);
                 plain_total += w.dst_capacity;
             }
         }
@@ -2570,8 +2611,49 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
     ORCD_TRY(dev_alloc(c, std::max<uint64_t>(plain_total, 256), &stripe_mem.tmp));
     ORCD_TRY(run_moves(c, stored, d_raw, (uint8_t *)stripe_mem.tmp));
     std::vector<uint32_t> sizes(work.size());
-    ORCD_TRY(inflate_device(c, d_raw, raw_total, work.data(), work.size(), (uint8_t *)stripe_mem.tmp,
-                            plain_total, sizes.data()));  // (waits for the stream)
+    {
+        // the host's share (see split_for_host) is inflated by its threads while the GPU does its own
+        const std::vector<char> to_host = split_for_host(work);
+        std::vector<orcd_chunk> gpu_work;
+        std::vector<size_t> gpu_at, host_at;
+        std::vector<orcd_internal_host_chunk> host_work;
+        for (size_t k = 0; k < work.size(); k++) {
+            if (to_host[k]) {
+                host_at.push_back(k);
+                host_work.push_back({work_host[k], work[k].src_length, work[k].dst_capacity});
+            } else {
+                gpu_at.push_back(k);
+                gpu_work.push_back(work[k]);
+            }
+        }
+        std::vector<std::vector<uint8_t>> host_out;
+        std::vector<uint32_t> host_sizes(host_work.size()), gpu_sizes(gpu_work.size());
+        int host_rc = ORCD_OK;
+        std::thread helper;
+        if (!host_work.empty())
+            helper = std::thread([&] {
+                try {
+                    host_rc = orcd_internal_inflate_list(orcd_file_compression(file), host_work.data(), host_work.size(),
+                                                         host_out, host_sizes.data());
+                } catch (...) {
+                    host_rc = ORCD_NO_MEMORY;
+                }
+            });
+        const int gpu_rc = inflate_device(c, d_raw, raw_total, gpu_work.data(), gpu_work.size(), (uint8_t *)stripe_mem.tmp,
+                                          plain_total, gpu_sizes.data());  // (waits for the stream)
+        if (helper.joinable()) helper.join();
+        if (gpu_rc != ORCD_OK && gpu_rc != ORCD_DECOMPRESSION) return gpu_rc;
+        if (host_rc != ORCD_OK) return host_rc;
+        for (size_t j = 0; j < gpu_at.size(); j++) sizes[gpu_at[j]] = gpu_sizes[j];
+        for (size_t j = 0; j < host_at.size(); j++) sizes[host_at[j]] = host_sizes[j];
+        for (uint32_t s : sizes)
+            if (s == 0xFFFFFFFFu) return ORCD_DECOMPRESSION;
+        for (size_t j = 0; j < host_at.size(); j++)
+            if (host_sizes[j])
+                HIP_TRY(c, hipMemcpyAsync((uint8_t *)stripe_mem.tmp + work[host_at[j]].dst_offset, host_out[j].data(),
+                                          host_sizes[j], hipMemcpyHostToDevice, c->stream));
+        if (!host_at.empty()) HIP_TRY(c, hipStreamSynchronize(c->stream));  // (host_out goes away)
+    }
 
     // where everything came to lie; a chunk that did not fill its place -- other than a stream's
     // last -- leaves a gap, and then the chunks are moved together

@@ -446,6 +446,43 @@ int inflate_chunks(int codec, const uint8_t *src, size_t n, uint64_t block, std:
     return ORCD_OK;
 }
 
+}  // namespace
+
+extern "C" int orcd_internal_inflate_list(int codec, const orcd_internal_host_chunk *list, size_t n,
+                               std::vector<std::vector<uint8_t>> &out, uint32_t *sizes) {
+    out.assign(n, {});
+    std::atomic<size_t> next{0};
+    std::atomic<int> stopped{ORCD_OK};
+    auto work = [&]() {
+        for (size_t k; (k = next.fetch_add(1)) < n && stopped == ORCD_OK;) {
+            int rc;
+            try {
+                rc = decompress_one(codec, list[k].src, list[k].len, list[k].cap, out[k]);
+            } catch (const std::bad_alloc &) {
+                rc = ORCD_NO_MEMORY;
+            }
+            if (rc == ORCD_OK) sizes[k] = (uint32_t)out[k].size();
+            else if (rc == ORCD_DECOMPRESSION) sizes[k] = 0xFFFFFFFFu;
+            else stopped = rc;
+        }
+    };
+    unsigned n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), INFLATE_MAX_THREADS);
+    n_threads = (unsigned)std::min<size_t>(n_threads, std::max<size_t>(n, 1));
+    std::vector<std::thread> threads;
+    for (unsigned i = 1; i < n_threads; i++) {
+        try {
+            threads.emplace_back(work);
+        } catch (...) {
+            break;  // as many as can be had; this thread works too
+        }
+    }
+    work();
+    for (auto &th : threads) th.join();
+    return stopped;
+}
+
+namespace {
+
 // A footer-like section as the protobuf reader wants it: the bytes themselves, or decompressed
 // (src/read/mod.rs:161-183).
 int plain_section(const orcd_file *f, const uint8_t *p, size_t n, std::vector<uint8_t> &out);

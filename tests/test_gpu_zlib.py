@@ -10,14 +10,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["host", "device"])
+@pytest.fixture(autouse=True, params=["host", "device", "both"])
 def inflate_where(request, monkeypatch):
-    """Every test twice: the chunks inflated by the host's zlib, and by the GPU (which by itself
-    takes over only when a stripe holds many chunks)."""
+    """Every test three times: the chunks inflated by the host's zlib, by the GPU (which by itself
+    takes over only when a stripe holds many chunks), and every other chunk by each (by itself
+    the library gives the host the chunks the GPU would take longest over)."""
     if request.param == "host":
         monkeypatch.setenv("ORCD_GPU_INFLATE", "0")
     else:
         monkeypatch.setenv("ORCD_GPU_INFLATE_MIN_CHUNKS", "1")
+        monkeypatch.setenv("ORCD_GPU_INFLATE_SPLIT", "0" if request.param == "device" else "2")
     return request.param
 
 
