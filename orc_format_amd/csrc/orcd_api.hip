@@ -211,7 +211,8 @@ struct PrefetchJob {
     // a compressed file: the bytes stay in host memory as well (the decode call walks the chunk
     // headers there)
     bool keep_host = false;
-    std::vector<uint8_t> host;
+    void *host = nullptr;  // pinned, from the prefetcher's pool
+    size_t host_cap = 0;
     int status = ORCD_OK;
     bool done = false;
 };
@@ -227,6 +228,10 @@ struct Prefetcher {
     std::deque<PrefetchJob *> jobs;  // queued, being read, or read and not yet claimed -- oldest first
     bool stop = false;
     StageSet stage;
+    // pinned host blocks for the stripes of compressed files (read into by several threads, copied
+    // to the device in one piece, kept for the decode call): handed out and taken back under `m`
+    std::vector<std::pair<void *, size_t>> pinned;
+    static constexpr size_t MAX_PINNED = 3;
 };
 
 // ---- device memory of orcd_rlev2_decode_noalloc ------------------------------------------------
@@ -292,6 +297,7 @@ struct orcd_ctx {
     uint32_t totals_stamp = 0;
     uint64_t *h_scalars = nullptr;   // pinned, 8 words
     StageSet stage;                    // large host transfers of the calling thread, queued on `stream`
+    std::vector<uint8_t> inflate_scratch;  // where the host's threads leave the chunks they inflate (kept: its pages stay)
     Prefetcher *prefetcher = nullptr;  // background reader of stripes to come (orcd_stripe_prefetch)
     // Result arrays and per-call temporaries of the column calls: released blocks are kept and
     // handed out again (see dev_alloc).
@@ -2013,6 +2019,70 @@ void dev_free(orcd_ctx *c, void *p) {
 // orcd_decode_stripe, when it finds the region it needs among the jobs, waits for that job instead
 // of reading.  Jobs are served oldest first, at most Prefetcher::MAX_JOBS are kept.
 
+// A pinned block of at least `len` bytes from the prefetcher's pool (a new one when none fits).
+void *pinned_take(Prefetcher *pf, size_t len, size_t *cap) {
+    {
+        std::lock_guard<std::mutex> lock(pf->m);
+        for (size_t i = 0; i < pf->pinned.size(); i++)
+            if (pf->pinned[i].second >= len) {
+                void *p = pf->pinned[i].first;
+                *cap = pf->pinned[i].second;
+                pf->pinned.erase(pf->pinned.begin() + i);
+                return p;
+            }
+    }
+    void *p = nullptr;
+    const size_t want = len + len / 4 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    *cap = want;
+    return p;
+}
+
+void pinned_give_back(Prefetcher *pf, void *p, size_t cap) {
+    if (!p) return;
+    void *drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(pf->m);
+        pf->pinned.push_back({p, cap});
+        if (pf->pinned.size() > Prefetcher::MAX_PINNED) {  // the smallest goes
+            size_t least = 0;
+            for (size_t i = 1; i < pf->pinned.size(); i++)
+                if (pf->pinned[i].second < pf->pinned[least].second) least = i;
+            drop = pf->pinned[least].first;
+            pf->pinned.erase(pf->pinned.begin() + least);
+        }
+    }
+    if (drop) (void)hipHostFree(drop);
+}
+
+// file[off, off + len) into dst, by PINNED_READERS threads a slice each (positioned reads: the page
+// cache gives one thread a few GB/s).
+constexpr int PINNED_READERS = 4;
+int read_in_slices(orcd_file *file, uint64_t off, uint64_t len, uint8_t *dst) {
+    const uint64_t slice = ((len + PINNED_READERS - 1) / PINNED_READERS + 4095) & ~(uint64_t)4095;
+    int status[PINNED_READERS];
+    std::vector<std::thread> threads;
+    auto work = [&](int i) {
+        const uint64_t lo = std::min<uint64_t>(len, (uint64_t)i * slice), hi = std::min<uint64_t>(len, lo + slice);
+        status[i] = hi > lo ? orcd_file_read_at(file, off + lo, hi - lo, dst + lo) : ORCD_OK;
+    };
+    for (int i = 1; i < PINNED_READERS; i++) {
+        status[i] = -1;
+        try {
+            threads.emplace_back(work, i);
+        } catch (...) {
+            break;
+        }
+    }
+    work(0);
+    for (auto &th : threads) th.join();
+    for (int i = 1; i < PINNED_READERS; i++)
+        if (status[i] == -1) work(i);  // (a thread that could not be had: this one does its slice)
+    for (int i = 0; i < PINNED_READERS; i++)
+        if (status[i] != ORCD_OK) return status[i];
+    return ORCD_OK;
+}
+
 void prefetch_serve(orcd_ctx *c) {
     Prefetcher *pf = c->prefetcher;
     (void)hipSetDevice(c->device);
@@ -2035,14 +2105,12 @@ void prefetch_serve(orcd_ctx *c) {
         }
         int rc = ORCD_OK;
         if (job->keep_host) {
-            try {
-                job->host.resize(job->len);
-                rc = orcd_file_read_at(job->file, job->file_off, job->len, job->host.data());
-            } catch (const std::bad_alloc &) {
-                rc = ORCD_NO_MEMORY;
-            }
-            const HostSource region = {nullptr, 0, job->host.data()};
-            if (rc == ORCD_OK) rc = chunked_to_device(c, pf->stage, region, job->len, (uint8_t *)job->d_buf);
+            job->host = pinned_take(pf, job->len, &job->host_cap);
+            if (!job->host) rc = ORCD_NO_MEMORY;
+            if (rc == ORCD_OK) rc = read_in_slices(job->file, job->file_off, job->len, (uint8_t *)job->host);
+            if (rc == ORCD_OK && hipMemcpyAsync(job->d_buf, job->host, job->len, hipMemcpyHostToDevice,
+                                                pf->stage.stream) != hipSuccess)
+                rc = ORCD_HIP_ERROR;
         } else {
             const HostSource region = {job->file, job->file_off, nullptr};
             rc = chunked_to_device(c, pf->stage, region, job->len, (uint8_t *)job->d_buf);
@@ -2083,9 +2151,12 @@ void prefetch_shutdown(orcd_ctx *c) {
     if (pf->worker.joinable()) pf->worker.join();  // (a read that is under way finishes first)
     for (PrefetchJob *j : pf->jobs) {
         dev_free(c, j->d_buf);
+        if (j->host) (void)hipHostFree(j->host);
         delete j;
     }
     pf->jobs.clear();
+    for (auto &b : pf->pinned) (void)hipHostFree(b.first);
+    pf->pinned.clear();
     if (pf->stage.stream) {
         (void)hipStreamSynchronize(pf->stage.stream);
         pf->stage.release();
@@ -2098,8 +2169,10 @@ void prefetch_shutdown(orcd_ctx *c) {
 // The device copy of file[file_off, file_off + len) of `stripe`, if it was asked for ahead of
 // time: waits for the read, hands the block over (the caller owns it then) or returns null (never
 // asked for, or the read failed: the caller reads for itself and reports what it finds).
+// (host, host_cap: where the job's pinned host copy goes -- the caller gives it back with
+// pinned_give_back; a caller that does not take it leaves it to the pool)
 void *prefetch_claim(orcd_ctx *c, orcd_file *file, size_t stripe, uint64_t file_off, uint64_t len,
-                     std::vector<uint8_t> *host = nullptr) {
+                     void **host = nullptr, size_t *host_cap = nullptr) {
     Prefetcher *pf = c->prefetcher;
     if (!pf) return nullptr;
     std::unique_lock<std::mutex> lock(pf->m);
@@ -2110,10 +2183,17 @@ void *prefetch_claim(orcd_ctx *c, orcd_file *file, size_t stripe, uint64_t file_
         pf->jobs.erase(it);
         void *buf = j->d_buf;
         const int rc = j->status;
-        if (host) host->swap(j->host);
+        void *hp = j->host;
+        const size_t hc = j->host_cap;
         delete j;
+        lock.unlock();
+        if (rc != ORCD_OK || !host) {
+            pinned_give_back(pf, hp, hc);
+        } else {
+            *host = hp;
+            *host_cap = hc;
+        }
         if (rc != ORCD_OK) {
-            lock.unlock();
             dev_free(c, buf);
             return nullptr;
         }
@@ -2626,7 +2706,11 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
                 gpu_work.push_back(work[k]);
             }
         }
-        std::vector<std::vector<uint8_t>> host_out;
+        // (the host's chunks land a block apart in one piece of host memory the context keeps, go to
+        // the device in one copy, and are moved to their places there)
+        const size_t pitch = (size_t)block;
+        if (c->inflate_scratch.size() < host_work.size() * pitch) c->inflate_scratch.resize(host_work.size() * pitch);
+        uint8_t *host_out = c->inflate_scratch.data();
         std::vector<uint32_t> host_sizes(host_work.size()), gpu_sizes(gpu_work.size());
         int host_rc = ORCD_OK;
         std::thread helper;
@@ -2634,7 +2718,7 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
             helper = std::thread([&] {
                 try {
                     host_rc = orcd_internal_inflate_list(orcd_file_compression(file), host_work.data(), host_work.size(),
-                                                         host_out, host_sizes.data());
+                                                         host_out, pitch, host_sizes.data());
                 } catch (...) {
                     host_rc = ORCD_NO_MEMORY;
                 }
@@ -2648,11 +2732,17 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
         for (size_t j = 0; j < host_at.size(); j++) sizes[host_at[j]] = host_sizes[j];
         for (uint32_t s : sizes)
             if (s == 0xFFFFFFFFu) return ORCD_DECOMPRESSION;
-        for (size_t j = 0; j < host_at.size(); j++)
-            if (host_sizes[j])
-                HIP_TRY(c, hipMemcpyAsync((uint8_t *)stripe_mem.tmp + work[host_at[j]].dst_offset, host_out[j].data(),
-                                          host_sizes[j], hipMemcpyHostToDevice, c->stream));
-        if (!host_at.empty()) HIP_TRY(c, hipStreamSynchronize(c->stream));  // (host_out goes away)
+        if (!host_at.empty()) {
+            Pending staged(c);
+            ORCD_TRY(dev_alloc(c, host_at.size() * pitch, &staged.tmp));
+            const HostSource from = {nullptr, 0, host_out};
+            ORCD_TRY(chunked_to_device(c, from, host_at.size() * pitch, (uint8_t *)staged.tmp));
+            std::vector<InflateMove> places;
+            for (size_t j = 0; j < host_at.size(); j++)
+                add_move(places, j * pitch, work[host_at[j]].dst_offset, host_sizes[j]);
+            ORCD_TRY(run_moves(c, places, (const uint8_t *)staged.tmp, (uint8_t *)stripe_mem.tmp));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));  // (the staging block and the table of moves go away)
+        }
     }
 
     // where everything came to lie; a chunk that did not fill its place -- other than a stream's
@@ -2715,15 +2805,23 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     const bool compressed = orcd_file_compression(file) != 0;
     // a compressed stripe that was read ahead of time (orcd_stripe_prefetch): its bytes are in host
     // memory, for the walk over the chunk headers, and on the device, for the inflate
-    std::vector<uint8_t> ahead_host;
+    struct HostAhead {  // (back to the prefetcher's pool when the call is over)
+        orcd_ctx *c;
+        void *p = nullptr;
+        size_t cap = 0;
+        ~HostAhead() {
+            if (p && c->prefetcher) pinned_give_back(c->prefetcher, p, cap);
+            else if (p) (void)hipHostFree(p);
+        }
+    } ahead_host{c};
     Pending ahead(c);
     uint64_t ahead_at = 0, ahead_len = 0;
     if (compressed && c->prefetcher) {
         for (size_t i = 0; i < n_columns; i++)
             if (columns[i] >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
         if (stripe_columns_region(file, stripe, footer, columns, n_columns, &ahead_at, &ahead_len) == ORCD_OK && ahead_len)
-            ahead.tmp = prefetch_claim(c, file, stripe, ahead_at, ahead_len, &ahead_host);
-        if (ahead.tmp && ahead_host.size() != ahead_len) {  // (not a job of the compressed kind)
+            ahead.tmp = prefetch_claim(c, file, stripe, ahead_at, ahead_len, &ahead_host.p, &ahead_host.cap);
+        if (ahead.tmp && !ahead_host.p) {  // (not a job of the compressed kind)
             dev_free(c, ahead.tmp);
             ahead.tmp = nullptr;
         }
@@ -2734,14 +2832,14 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
         // (a compressed file: the host reads each column's region and finds its compression chunks;
         // they are decompressed below, src/read/decompress/mod.rs:60-80, on the device or the host)
         if (compressed)
-            ORCD_TRY(orcd_internal_column_raw_from(file, stripe, footer, columns[i], ahead.tmp ? ahead_host.data() : nullptr,
+            ORCD_TRY(orcd_internal_column_raw_from(file, stripe, footer, columns[i], ahead.tmp ? (const uint8_t *)ahead_host.p : nullptr,
                                                    ahead_at, ahead_len, &(*jobs[i]).col));
         else ORCD_TRY(orcd_stripe_column_open(file, stripe, footer, columns[i], &(*jobs[i]).col));
     }
     StripeBytes sb;
     if (compressed)
         ORCD_TRY(compressed_columns_to_device(c, file, jobs, n_columns, stripe_mem, (const uint8_t *)ahead.tmp,
-                                              ahead.tmp ? ahead_host.data() : nullptr));
+                                              ahead.tmp ? (const uint8_t *)ahead_host.p : nullptr));
     sb.lo = ~0ull;
     for (size_t i = 0; i < n_columns && !compressed; i++) {
         uint64_t off = 0, n = 0;
@@ -2907,7 +3005,8 @@ int orcd_stripe_prefetch(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd
     DeviceGuard g(c->device);
     ORCD_TRY(prefetch_start(c));
     Prefetcher *pf = c->prefetcher;
-    void *stale = nullptr;
+    void *stale = nullptr, *stale_host = nullptr;
+    size_t stale_cap = 0;
     {
         std::lock_guard<std::mutex> lock(pf->m);
         for (PrefetchJob *j : pf->jobs)
@@ -2918,11 +3017,14 @@ int orcd_stripe_prefetch(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd
             PrefetchJob *oldest = pf->jobs.front();
             if (!oldest->done) return ORCD_OK;
             stale = oldest->d_buf;
+            stale_host = oldest->host;
+            stale_cap = oldest->host_cap;
             pf->jobs.pop_front();
             delete oldest;
         }
     }
     dev_free(c, stale);
+    pinned_give_back(pf, stale_host, stale_cap);
     std::unique_ptr<PrefetchJob> job(new PrefetchJob());
     job->file = file;
     job->stripe = stripe;

@@ -30,15 +30,13 @@ extern "C" int orcd_internal_column_set_plain(orcd_column *col, const uint64_t *
                                               const uint64_t *chunk_off);
 extern "C" int orcd_internal_column_plain_range(const orcd_column *col, int kind, uint64_t *off, uint64_t *len);
 extern "C" uint64_t orcd_internal_file_compression_block(const orcd_file *f);
-// Chunks of a compressed region inflated by the host's threads, each into a buffer of its own:
-// chunk k is src[0, len) and may decompress to at most `cap` bytes; sizes[k] receives what it came
-// to, or 0xFFFFFFFF when it does not decompress.  Returns ORCD_OK, or what stopped the work as a
-// whole (no memory, a codec that cannot be had).
+// Chunks of a compressed region inflated by the host's threads: chunk k is src[0, len), may
+// decompress to at most `cap` bytes (and `pitch`), and its bytes go to out + k * pitch; sizes[k]
+// receives what it came to, or 0xFFFFFFFF when it does not decompress.  Returns ORCD_OK, or what
+// stopped the work as a whole (no memory, a codec that cannot be had).
 struct orcd_internal_host_chunk {
     const uint8_t *src;
     uint32_t len, cap;
 };
-#include <vector>
-extern "C" int orcd_internal_inflate_list(int codec, const orcd_internal_host_chunk *list, size_t n,
-                               std::vector<std::vector<uint8_t>> &out, uint32_t *sizes);
-
+extern "C" int orcd_internal_inflate_list(int codec, const orcd_internal_host_chunk *list, size_t n, uint8_t *out,
+                                          size_t pitch, uint32_t *sizes);

@@ -449,21 +449,26 @@ int inflate_chunks(int codec, const uint8_t *src, size_t n, uint64_t block, std:
 }  // namespace
 
 extern "C" int orcd_internal_inflate_list(int codec, const orcd_internal_host_chunk *list, size_t n,
-                               std::vector<std::vector<uint8_t>> &out, uint32_t *sizes) {
-    out.assign(n, {});
+                               uint8_t *out, size_t pitch, uint32_t *sizes) {
     std::atomic<size_t> next{0};
     std::atomic<int> stopped{ORCD_OK};
     auto work = [&]() {
         for (size_t k; (k = next.fetch_add(1)) < n && stopped == ORCD_OK;) {
             int rc;
+            std::vector<uint8_t> plain;
             try {
-                rc = decompress_one(codec, list[k].src, list[k].len, list[k].cap, out[k]);
+                rc = decompress_one(codec, list[k].src, list[k].len, std::min<uint64_t>(list[k].cap, pitch), plain);
             } catch (const std::bad_alloc &) {
                 rc = ORCD_NO_MEMORY;
             }
-            if (rc == ORCD_OK) sizes[k] = (uint32_t)out[k].size();
-            else if (rc == ORCD_DECOMPRESSION) sizes[k] = 0xFFFFFFFFu;
-            else stopped = rc;
+            if (rc == ORCD_OK && plain.size() <= pitch) {
+                sizes[k] = (uint32_t)plain.size();
+                if (!plain.empty()) memcpy(out + k * pitch, plain.data(), plain.size());
+            } else if (rc == ORCD_OK || rc == ORCD_DECOMPRESSION) {
+                sizes[k] = 0xFFFFFFFFu;
+            } else {
+                stopped = rc;
+            }
         }
     };
     unsigned n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), INFLATE_MAX_THREADS);
