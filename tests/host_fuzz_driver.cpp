@@ -68,6 +68,20 @@ static int walk(const std::vector<uint8_t> &image) {
                     if (chunks[j].stream >= n_streams || chunks[j].at > len || chunks[j].len > len - chunks[j].at) return 97;
                     if (chunks[j].len) checksum += bytes[chunks[j].at] + bytes[chunks[j].at + chunks[j].len - 1];
                 }
+                if (way == 1) {  // the host's share of a split inflate: every chunk into a slot of its own
+                    std::vector<orcd_internal_host_chunk> list;
+                    for (size_t j = 0; j < n_chunks && list.size() < 64; j++)
+                        if (!chunks[j].original && chunks[j].len) list.push_back({bytes + chunks[j].at, chunks[j].len, 1u << 16});
+                    std::vector<uint8_t> slots(list.size() << 16);
+                    std::vector<uint32_t> sizes(list.size());
+                    if (!list.empty() && orcd_internal_inflate_list(orcd_file_compression(f), list.data(), list.size(),
+                                                                    slots.data(), 1u << 16, sizes.data()) == ORCD_OK)
+                        for (size_t j = 0; j < list.size(); j++)
+                            if (sizes[j] != 0xFFFFFFFFu) {
+                                if (sizes[j] > (1u << 16)) return 94;
+                                if (sizes[j]) checksum += slots[(j << 16) + sizes[j] - 1];
+                            }
+                }
                 if (way == 0) {
                     if (orcd_internal_column_inflate_host(f, raw) == ORCD_OK) {
                         uint64_t off, n;
