@@ -1964,8 +1964,8 @@ struct ColumnStreams {
     orcd_column *col;
     const StripeBytes *dev;  // the device copy the column's streams lie in
     // a compressed file: the column's streams lie decompressed on the device, stream k at
-    // plain_dev + the offset the column handle keeps for it (plain_host: unused)
-    const uint8_t *plain_dev = nullptr, *plain_host = nullptr;
+    // plain_dev + the offset the column handle keeps for it
+    const uint8_t *plain_dev = nullptr;
     // flags for the stream decoders: streams on the device, ROW_INDEX positions on the host,
     // results stay on the device
     unsigned io() const { return ORCD_OUT_DEVICE | ORCD_IN_DEVICE | ORCD_ENTRIES_HOST; }
@@ -2474,7 +2474,7 @@ struct StripeJob {
     int type_kind = 0;
     uint64_t n_values = 0;
     bool have_validity = false, batched = false;
-    const uint8_t *plain_dev = nullptr, *plain_host = nullptr;  // (see ColumnStreams)
+    const uint8_t *plain_dev = nullptr;  // (see ColumnStreams)
     Pending p;
     explicit StripeJob(orcd_ctx *c) : p(c) {}
 };
@@ -2870,7 +2870,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
         StreamBatch batch;
         uint64_t arena_bytes = 0;
         for (size_t i = 0; i < n_columns; i++) {
-            const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev, (*jobs[i]).plain_host};
+            const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev};
             const uint64_t rows = orcd_column_number_of_rows((*jobs[i]).col);
             const uint8_t *b;
             size_t l, n_ent;
@@ -2906,7 +2906,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     }
     for (size_t i = 0; i < n_columns; i++) {
         if ((*jobs[i]).have_validity) continue;
-        const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev, (*jobs[i]).plain_host};
+        const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev};
         ORCD_TRY(column_validity(c, cs, (*jobs[i]).p, &(*jobs[i]).n_values));
     }
     // 3. the small DATA streams of the integer columns in one set of launches
@@ -2918,7 +2918,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
             int enc = 0;
             if (orcd_column_encoding((*jobs[i]).col, &enc, nullptr) != ORCD_OK || enc != ORCD_ENC_DIRECT_V2)
                 continue;  // RLE v1 or unknown: reported per column below
-            const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev, (*jobs[i]).plain_host};
+            const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev};
             const uint8_t *b;
             size_t l, n_ent;
             const uint64_t *ent;
@@ -2954,7 +2954,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     }
     // 4. everything else, column by column
     for (size_t i = 0; i < n_columns; i++) {
-        const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev, (*jobs[i]).plain_host};
+        const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev};
         ORCD_TRY(column_values(c, cs, (*jobs[i]).type_kind, flags, (*jobs[i]).p, (*jobs[i]).n_values, (*jobs[i]).batched,
                                &out[i]));
     }
