@@ -1079,6 +1079,7 @@ int orcd_ctx_release_cached(orcd_ctx *c) try {
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // queued work may still use a released block
     c->dev_cache.release_all();
     c->host_cache.release_all();
+    std::vector<uint8_t>().swap(c->inflate_scratch);
     return ORCD_OK;
 } ORCD_CATCH
 
