@@ -2059,6 +2059,7 @@ void pinned_give_back(Prefetcher *pf, void *p, size_t cap) {
 // file[off, off + len) into dst, by PINNED_READERS threads a slice each (positioned reads: the page
 // cache gives one thread a few GB/s).
 constexpr int PINNED_READERS = 4;
+constexpr uint64_t PINNED_READ_MIN = 4u << 20;  // smaller regions are read the plain way
 int read_in_slices(orcd_file *file, uint64_t off, uint64_t len, uint8_t *dst) {
     const uint64_t slice = ((len + PINNED_READERS - 1) / PINNED_READERS + 4095) & ~(uint64_t)4095;
     int status[PINNED_READERS];
@@ -2817,14 +2818,30 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     } ahead_host{c};
     Pending ahead(c);
     uint64_t ahead_at = 0, ahead_len = 0;
-    if (compressed && c->prefetcher) {
+    if (compressed && orcd_file_compression(file) == 1 && gpu_inflate_min_chunks() != ~(size_t)0) {
         for (size_t i = 0; i < n_columns; i++)
             if (columns[i] >= orcd_file_num_types(file)) return ORCD_INVALID_COLUMN;
-        if (stripe_columns_region(file, stripe, footer, columns, n_columns, &ahead_at, &ahead_len) == ORCD_OK && ahead_len)
+        const bool known = stripe_columns_region(file, stripe, footer, columns, n_columns, &ahead_at, &ahead_len) == ORCD_OK &&
+                           ahead_len;
+        if (known && c->prefetcher)
             ahead.tmp = prefetch_claim(c, file, stripe, ahead_at, ahead_len, &ahead_host.p, &ahead_host.cap);
         if (ahead.tmp && !ahead_host.p) {  // (not a job of the compressed kind)
             dev_free(c, ahead.tmp);
             ahead.tmp = nullptr;
+        }
+        // nothing was read ahead: the same now -- the region into a pinned block by several
+        // threads, to the device in one piece (when anything of this fails, the columns read
+        // for themselves below and say what is wrong)
+        if (known && !ahead.tmp && ahead_len >= PINNED_READ_MIN && prefetch_start(c) == ORCD_OK) {
+            ahead_host.p = pinned_take(c->prefetcher, ahead_len, &ahead_host.cap);
+            bool fine = ahead_host.p && read_in_slices(file, ahead_at, ahead_len, (uint8_t *)ahead_host.p) == ORCD_OK &&
+                        dev_alloc(c, ahead_len, &ahead.tmp) == ORCD_OK;
+            if (fine && hipMemcpyAsync(ahead.tmp, ahead_host.p, ahead_len, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+                fine = false;
+            if (!fine) {
+                dev_free(c, ahead.tmp);
+                ahead.tmp = nullptr;
+            }
         }
     }
     for (size_t i = 0; i < n_columns; i++) {
