@@ -2725,8 +2725,13 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
                     host_rc = ORCD_NO_MEMORY;
                 }
             });
-        const int gpu_rc = inflate_device(c, d_raw, raw_total, gpu_work.data(), gpu_work.size(), (uint8_t *)stripe_mem.tmp,
-                                          plain_total, gpu_sizes.data());  // (waits for the stream)
+        int gpu_rc;
+        try {
+            gpu_rc = inflate_device(c, d_raw, raw_total, gpu_work.data(), gpu_work.size(), (uint8_t *)stripe_mem.tmp,
+                                    plain_total, gpu_sizes.data());  // (waits for the stream)
+        } catch (...) {  // (the helper must be joined whatever happens here)
+            gpu_rc = ORCD_NO_MEMORY;
+        }
         if (helper.joinable()) helper.join();
         if (gpu_rc != ORCD_OK && gpu_rc != ORCD_DECOMPRESSION) return gpu_rc;
         if (host_rc != ORCD_OK) return host_rc;
