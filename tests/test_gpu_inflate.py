@@ -229,3 +229,20 @@ def test_damaged_zlib_files_decode_alike_on_both_paths(tmp_path, monkeypatch):
             else:
                 same_bad += 1
     assert same_ok > 5 and same_bad > 5
+
+
+def test_chunk_tables_that_do_not_fit_are_refused_before_anything_runs(ctx):
+    from orc_format_amd.error import OrcError
+    raw = deflate(b"abc" * 100)
+    for chunks, dst_len in (
+        ([(0, len(raw) + 1, 0, 300)], 300),        # more bytes than the source holds
+        ([(len(raw) + 5, 1, 0, 300)], 300),        # starts past its end
+        ([(0, len(raw), 0, 301)], 300),            # more room than the destination has
+        ([(0, len(raw), 400, 10)], 300),           # a place past its end
+    ):
+        with pytest.raises(OrcError) as e:
+            ctx.inflate_chunks(raw, chunks, dst_len)
+        assert e.value.code == 102, chunks
+    out, sizes = ctx.inflate_chunks(raw, [], 16)   # nothing to do
+    assert sizes.size == 0
+    assert run(ctx, [b""], 16)[0] == 6             # an empty stream is no deflate stream (zlib: the same)
