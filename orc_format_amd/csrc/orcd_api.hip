@@ -2546,6 +2546,7 @@ size_t gpu_inflate_min_chunks() {
 // ORCD_GPU_INFLATE_SPLIT=0: everything to the GPU; =2: every other chunk to the host (tests).
 constexpr double GPU_US_PER_BYTE = 0.165, HOST_US_PER_BYTE = 1.0 / 400.0;
 constexpr size_t INFLATE_PLACES = 768;
+constexpr uint64_t HOST_SHARE_MAX = 1ull << 30;
 
 std::vector<char> split_for_host(const std::vector<orcd_chunk> &work) {
     std::vector<char> to_host(work.size(), 0);
@@ -2616,7 +2617,11 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
         r.at = raw_total;
         raw_total += (r.len + 255) & ~(uint64_t)255;
     }
-    if (orcd_file_compression(file) != 1 || deflated < gpu_inflate_min_chunks()) {
+    // (a chunk's header has 23 bits for its length, and no writer makes chunks larger than the
+    // compression block: a PostScript that claims more than that is left to the host's inflate,
+    // whose memory goes with what the chunks really hold)
+    const bool sane_block = orcd_internal_file_compression_block(file) <= (8u << 20);
+    if (orcd_file_compression(file) != 1 || deflated < gpu_inflate_min_chunks() || !sane_block) {
         // the host's threads decompress; the plain streams go to the device as they are
         uint64_t total = 0;
         std::vector<uint64_t> at(n_columns);
@@ -2695,7 +2700,15 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
     std::vector<uint32_t> sizes(work.size());
     {
         // the host's share (see split_for_host) is inflated by its threads while the GPU does its own
-        const std::vector<char> to_host = split_for_host(work);
+        std::vector<char> to_host = split_for_host(work);
+        {   // (the host's chunks wait a block apart in host memory: no more than HOST_SHARE_MAX of it)
+            size_t allowed = (size_t)(HOST_SHARE_MAX / block);
+            for (size_t k = 0; k < to_host.size(); k++)
+                if (to_host[k]) {
+                    if (allowed) allowed--;
+                    else to_host[k] = 0;
+                }
+        }
         std::vector<orcd_chunk> gpu_work;
         std::vector<size_t> gpu_at, host_at;
         std::vector<orcd_internal_host_chunk> host_work;
