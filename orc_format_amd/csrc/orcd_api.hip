@@ -2620,7 +2620,7 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
     // (a chunk's header has 23 bits for its length, and no writer makes chunks larger than the
     // compression block: a PostScript that claims more than that is left to the host's inflate,
     // whose memory goes with what the chunks really hold)
-    const bool sane_block = orcd_internal_file_compression_block(file) <= (8u << 20);
+    const bool sane_block = orcd_internal_file_compression_block(file) >= 1 && orcd_internal_file_compression_block(file) <= (8u << 20);
     if (orcd_file_compression(file) != 1 || deflated < gpu_inflate_min_chunks() || !sane_block) {
         // the host's threads decompress; the plain streams go to the device as they are
         uint64_t total = 0;
