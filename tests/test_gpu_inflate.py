@@ -229,6 +229,19 @@ def test_damaged_zlib_files_decode_alike_on_both_paths(tmp_path, monkeypatch):
             else:
                 same_bad += 1
     assert same_ok > 5 and same_bad > 5
+    # the PostScript's compression block size changed under the chunks: one byte too small, tiny,
+    # zero, larger than any chunk
+    ps = len(image) - 1 - image[-1]
+    at = bytes(image).find(b"\x18\x80\x80\x04", ps)
+    assert at >= 0
+    for claim in (b"\xff\xff\x03", b"\x81\x80\x00", b"\x80\x80\x00", b"\xff\xff\x7f"):
+        blob = bytearray(image)
+        blob[at + 1:at + 4] = claim
+        a, b, both = decode(bytes(blob), "host"), decode(bytes(blob), "device"), decode(bytes(blob), "both")
+        assert [x[:2] for x in a] == [x[:2] for x in b] == [x[:2] for x in both], claim
+        for x, y, z in zip(a, b, both):
+            if x[1] == 0 and x[0] != "open":
+                assert x[2] == y[2] == z[2], claim
 
 
 def test_chunk_tables_that_do_not_fit_are_refused_before_anything_runs(ctx):
