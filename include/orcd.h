@@ -148,7 +148,7 @@ int orcd_rlev2_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t n
  * to and the room there (the file's compression block size: a chunk that decompresses to more does
  * not inflate).  sizes[k] (host memory) receives the bytes chunk k decompressed to, or 0xFFFFFFFF;
  * the call returns ORCD_DECOMPRESSION when any chunk does not inflate -- the same chunks as zlib
- * refuses.  Flags: ORCD_IN_DEVICE (src), ORCD_OUT_DEVICE (dst); `chunks` and `sizes` are host
+ * refuses -- and the chunks that did are in dst all the same.  Flags: ORCD_IN_DEVICE (src), ORCD_OUT_DEVICE (dst); `chunks` and `sizes` are host
  * memory.  The places in dst must not overlap. */
 typedef struct {
     uint64_t src_offset;

@@ -1203,13 +1203,13 @@ int orcd_inflate_chunks(orcd_ctx *c, const uint8_t *src, size_t src_len, const o
     mark(c, 1);
     const int rc = inflate_device(c, (const uint8_t *)d_src, src_len, chunks, n_chunks, d_dst, dst_len, sizes);
     mark(c, 3);
-    if (rc != ORCD_OK) return rc;
+    if (rc != ORCD_OK && rc != ORCD_DECOMPRESSION) return rc;
     if (!out_dev)  // (only the bytes that were written: the rest of the staging block is not the caller's)
         for (size_t k = 0; k < n_chunks; k++)
-            if (sizes[k]) HIP_TRY(c, hipMemcpyAsync(dst + chunks[k].dst_offset, d_dst + chunks[k].dst_offset, sizes[k],
+            if (sizes[k] && sizes[k] != 0xFFFFFFFFu) HIP_TRY(c, hipMemcpyAsync(dst + chunks[k].dst_offset, d_dst + chunks[k].dst_offset, sizes[k],
                                                     hipMemcpyDeviceToHost, c->stream));
     if (!out_dev) HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return ORCD_OK;
+    return rc;
 } ORCD_CATCH
 
 int orcd_rlev1_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_values,

@@ -259,3 +259,49 @@ def test_chunk_tables_that_do_not_fit_are_refused_before_anything_runs(ctx):
     out, sizes = ctx.inflate_chunks(raw, [], 16)   # nothing to do
     assert sizes.size == 0
     assert run(ctx, [b""], 16)[0] == 6             # an empty stream is no deflate stream (zlib: the same)
+
+
+def test_thousands_of_random_and_half_valid_chunks_in_one_call(ctx):
+    """Bytes that are no deflate streams at all, valid streams with their tails replaced by noise,
+    and valid ones, 3000 in one launch: every chunk ends as zlib says (sizes[k] is 0xFFFFFFFF for
+    the ones that do not inflate), none hangs, and the good ones' bytes are right."""
+    import ctypes as C
+    from orc_format_amd import _native as N
+    rng = np.random.default_rng(21)
+    cap = 1 << 15
+    good = [deflate(bytes(rng.integers(0, 6, size=int(rng.integers(1, 20_000)), dtype=np.uint8))) for _ in range(40)]
+    raws = []
+    for k in range(3000):
+        kind = k % 3
+        if kind == 0:
+            raws.append(bytes(rng.integers(0, 256, size=int(rng.integers(1, 3000)), dtype=np.uint8)))
+        elif kind == 1:
+            g = bytearray(good[k % len(good)])
+            at = int(rng.integers(0, len(g)))
+            g[at:] = bytes(rng.integers(0, 256, size=len(g) - at, dtype=np.uint8))
+            raws.append(bytes(g))
+        else:
+            raws.append(good[k % len(good)])
+    src = b"".join(raws)
+    table = np.zeros(len(raws), dtype=[("src_offset", "<u8"), ("dst_offset", "<u8"), ("src_length", "<u4"),
+                                       ("dst_capacity", "<u4")])
+    at = 0
+    for k, r in enumerate(raws):
+        table[k] = (at, k * cap, len(r), cap)
+        at += len(r)
+    s = np.frombuffer(src, dtype=np.uint8)
+    out = np.zeros(len(raws) * cap, dtype=np.uint8)
+    sizes = np.zeros(len(raws), dtype=np.uint32)
+    rc = N.lib().orcd_inflate_chunks(ctx.handle, s.ctypes.data, s.size, table.ctypes.data, len(raws), out.ctypes.data,
+                                     out.size, sizes.ctypes.data, 0)
+    assert rc in (0, 6)
+    ok = bad = 0
+    for k, r in enumerate(raws):
+        want_ok, want = cpu_inflate(r, cap)
+        assert (sizes[k] != 0xFFFFFFFF) == want_ok, k
+        if want_ok:
+            assert out[k * cap:k * cap + int(sizes[k])].tobytes() == want, k
+        ok += want_ok
+        bad += not want_ok
+    assert rc == (6 if bad else 0)
+    assert ok >= 1000 and bad >= 1000
