@@ -2558,6 +2558,9 @@ std::vector<char> split_for_host(const std::vector<orcd_chunk> &work) {
         for (size_t k = 1; k < work.size(); k += 2) to_host[k] = 1;
         return to_host;
     }
+    double gpu_rate = GPU_US_PER_BYTE;
+    if (const char *e = getenv("ORCD_GPU_INFLATE_US_PER_BYTE"))  // (for measuring where the balance lies)
+        if (*e) gpu_rate = atof(e);
     std::vector<size_t> order(work.size());
     for (size_t k = 0; k < order.size(); k++) order[k] = k;
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return work[a].src_length > work[b].src_length; });
@@ -2567,7 +2570,7 @@ std::vector<char> split_for_host(const std::vector<orcd_chunk> &work) {
     // largest first: the host takes a chunk as long as it still ends before the GPU would
     for (size_t i = 0; i < order.size(); i++) {
         const orcd_chunk &w = work[order[i]];
-        const double gpu_us = std::max<double>(w.src_length, gpu_bytes / INFLATE_PLACES) * GPU_US_PER_BYTE;
+        const double gpu_us = std::max<double>(w.src_length, gpu_bytes / INFLATE_PLACES) * gpu_rate;
         const double host_next = host_us + (double)w.dst_capacity * HOST_US_PER_BYTE / threads;
         if (host_next >= gpu_us) break;
         to_host[order[i]] = 1;
