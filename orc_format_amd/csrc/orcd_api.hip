@@ -297,7 +297,11 @@ struct orcd_ctx {
     uint32_t totals_stamp = 0;
     uint64_t *h_scalars = nullptr;   // pinned, 8 words
     StageSet stage;                    // large host transfers of the calling thread, queued on `stream`
-    std::vector<uint8_t> inflate_scratch;  // where the host's threads leave the chunks they inflate (kept: its pages stay)
+    // where the host's threads leave the chunks they inflate: pinned when that can be had (one
+    // copy to the device then), kept from call to call
+    void *inflate_pinned = nullptr;
+    size_t inflate_pinned_cap = 0;
+    std::vector<uint8_t> inflate_scratch;
     Prefetcher *prefetcher = nullptr;  // background reader of stripes to come (orcd_stripe_prefetch)
     // Result arrays and per-call temporaries of the column calls: released blocks are kept and
     // handed out again (see dev_alloc).
@@ -1056,6 +1060,7 @@ int orcd_ctx_destroy(orcd_ctx *c) try {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->inflate_pinned) (void)hipHostFree(c->inflate_pinned);
     prefetch_shutdown(c);  // (joins the background reader; its device blocks go back to the cache)
     c->stage.release();
     c->dev_cache.release_all();
@@ -1080,6 +1085,9 @@ int orcd_ctx_release_cached(orcd_ctx *c) try {
     c->dev_cache.release_all();
     c->host_cache.release_all();
     std::vector<uint8_t>().swap(c->inflate_scratch);
+    if (c->inflate_pinned) (void)hipHostFree(c->inflate_pinned);
+    c->inflate_pinned = nullptr;
+    c->inflate_pinned_cap = 0;
     return ORCD_OK;
 } ORCD_CATCH
 
@@ -2727,8 +2735,18 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
         // (the host's chunks land a block apart in one piece of host memory the context keeps, go to
         // the device in one copy, and are moved to their places there)
         const size_t pitch = (size_t)block;
-        if (c->inflate_scratch.size() < host_work.size() * pitch) c->inflate_scratch.resize(host_work.size() * pitch);
-        uint8_t *host_out = c->inflate_scratch.data();
+        const size_t host_bytes = host_work.size() * pitch;
+        if (host_bytes > c->inflate_pinned_cap) {
+            if (c->inflate_pinned) (void)hipHostFree(c->inflate_pinned);
+            c->inflate_pinned = nullptr;
+            c->inflate_pinned_cap = 0;
+            const size_t want = host_bytes + host_bytes / 4;
+            if (hipHostMalloc(&c->inflate_pinned, want, hipHostMallocDefault) == hipSuccess) c->inflate_pinned_cap = want;
+            else c->inflate_pinned = nullptr;
+        }
+        const bool pinned = host_bytes && c->inflate_pinned;
+        if (!pinned && c->inflate_scratch.size() < host_bytes) c->inflate_scratch.resize(host_bytes);
+        uint8_t *host_out = pinned ? (uint8_t *)c->inflate_pinned : c->inflate_scratch.data();
         std::vector<uint32_t> host_sizes(host_work.size()), gpu_sizes(gpu_work.size());
         int host_rc = ORCD_OK;
         std::thread helper;
@@ -2757,9 +2775,13 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
             if (s == 0xFFFFFFFFu) return ORCD_DECOMPRESSION;
         if (!host_at.empty()) {
             Pending staged(c);
-            ORCD_TRY(dev_alloc(c, host_at.size() * pitch, &staged.tmp));
-            const HostSource from = {nullptr, 0, host_out};
-            ORCD_TRY(chunked_to_device(c, from, host_at.size() * pitch, (uint8_t *)staged.tmp));
+            ORCD_TRY(dev_alloc(c, host_bytes, &staged.tmp));
+            if (pinned) {
+                HIP_TRY(c, hipMemcpyAsync(staged.tmp, host_out, host_bytes, hipMemcpyHostToDevice, c->stream));
+            } else {
+                const HostSource from = {nullptr, 0, host_out};
+                ORCD_TRY(chunked_to_device(c, from, host_bytes, (uint8_t *)staged.tmp));
+            }
             std::vector<InflateMove> places;
             for (size_t j = 0; j < host_at.size(); j++)
                 add_move(places, j * pitch, work[host_at[j]].dst_offset, host_sizes[j]);
