@@ -2732,6 +2732,21 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
                 gpu_work.push_back(work[k]);
             }
         }
+        {   // the GPU starts workgroups in the order of the table: the longest chunks first, so that
+            // the last ones to start are the shortest
+            std::vector<size_t> order(gpu_work.size());
+            for (size_t k = 0; k < order.size(); k++) order[k] = k;
+            std::sort(order.begin(), order.end(),
+                      [&](size_t a, size_t b) { return gpu_work[a].src_length > gpu_work[b].src_length; });
+            std::vector<orcd_chunk> sorted_work(gpu_work.size());
+            std::vector<size_t> sorted_at(gpu_at.size());
+            for (size_t k = 0; k < order.size(); k++) {
+                sorted_work[k] = gpu_work[order[k]];
+                sorted_at[k] = gpu_at[order[k]];
+            }
+            gpu_work.swap(sorted_work);
+            gpu_at.swap(sorted_at);
+        }
         // (the host's chunks land a block apart in one piece of host memory the context keeps, go to
         // the device in one copy, and are moved to their places there)
         const size_t pitch = (size_t)block;
