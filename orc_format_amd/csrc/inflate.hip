@@ -329,6 +329,9 @@ __global__ __launch_bounds__(128) void inflate_chunks_pair_kernel(const uint8_t 
     }
 
     // ---- the first wavefront: bits to tokens ----
+    // (it is the one the chunk waits for: where it shares a SIMD with a token-taking wavefront, of
+    // this chunk or another, it goes first)
+    __builtin_amdgcn_s_setprio(1);
     uint32_t tail = 0;
     // room for `count` tokens (at most 64); false: the other wavefront has given up
     uint32_t head_seen = 0;  // (the other side's count when last looked at: it only grows)
