@@ -518,18 +518,34 @@ __global__ __launch_bounds__(128) void inflate_chunks_pair_kernel(const uint8_t 
                     }
                 }
             }
+            // The chain: which lanes' tokens are real.  A lone wavefront issues an instruction every
+            // five cycles or so, dependent or not, so what a token costs is the instructions spent
+            // on it: here a lane read, an add and the chain's bit, sixteen tokens at a stretch
+            // without a branch.  A lane that could not make out its bits steps past the end, and so
+            // stops the walk; it and the end of the block are dealt with afterwards.
+            const uint32_t step = (packed & 63) ? (packed & 63) : 64u;
             uint64_t chain = 0;  // the lanes whose tokens are real, but for the end of the block
             uint32_t s = 0;
             while (s < 64) {
-                const uint32_t tok = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)s);
-                if ((tok & 63) == 0) break;
-                if (((tok >> 6) & 3) == 1) {
-                    s += tok & 63;
-                    eob = true;
-                    break;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    chain |= s < 64 ? 1ull << s : 0ull;
+                    s += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)(s & 63));
                 }
-                chain |= 1ull << s;
-                s += tok & 63;
+            }
+            {   // (steps taken after the 64 bits were through have added to s: where the chain really ends)
+                const uint32_t last = 63 - (uint32_t)__builtin_clzll(chain);
+                s = last + (uint32_t)__builtin_amdgcn_readlane((int)step, (int)last);
+            }
+            {
+                const uint64_t stops = __ballot((packed & 63) == 0 || ((packed >> 6) & 3) == 1) & chain;
+                if (stops) {  // the chain ends there: before a lane without a token, after the end of the block
+                    const uint32_t e = (uint32_t)__builtin_ctzll(stops);
+                    const uint32_t tok = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)e);
+                    chain &= (1ull << e) - 1;
+                    s = e + (tok & 63);
+                    eob = (tok & 63) != 0;
+                }
             }
             if (chain) {
                 const uint32_t count = (uint32_t)__popcll(chain);
