@@ -141,7 +141,7 @@ int orcd_rlev2_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t n
                       const uint64_t *entry_points, size_t n_entries, int64_t *out,
                       unsigned flags);
 
-/* Compression chunks of a zlib file inflated on the device, a wavefront per chunk: what the crate's
+/* Compression chunks of a zlib file inflated on the device, a workgroup per chunk: what the crate's
  * Decompressor does one chunk at a time on the host (src/read/decompress/mod.rs:60-80: a chunk
  * whose header says "compressed" is a raw deflate stream, handed to flate2).  chunks[k] names the
  * deflate bytes of chunk k inside src (after its 3-byte header), the place in dst its output goes
