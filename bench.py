@@ -222,6 +222,8 @@ def bench_rlev2(args, rank, world, local_rank, dist, torch, np):
 
     for _ in range(args.warmup):
         step()
+    ctx.synchronize()
+    out.zero_()   # what the check below compares was written by the timed steps, not by the warm-up
     barrier()
     phase_ms = {1: 0.0, 2: 0.0, 3: 0.0}
     t0 = time.perf_counter()
@@ -292,20 +294,38 @@ def bench_rlev2(args, rank, world, local_rank, dist, torch, np):
 
 
 def attach_traffic(result, workload, kernel):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary."""
+    """What the newest committed rocprofv3 summary of this workload (profiles/) says about the
+    dominant kernel, beside what this run measured itself:
+      traffic           HBM bytes per launch from the PMC passes (counters cannot be read in here);
+      frac_profiles     algorithmic bytes / the summary's average duration under --kernel-trace / peak
+                        -- another run, usually on another box, and 2-3 % long under the tracer;
+      profiles_unprofiled_same_lease   the same bench command without the profiler, run in the
+                        lease the summary was taken in, so that box and tracer can be told apart.
+    `frac`, `achieved` and `avg_launch_ms` are always this run's own HIP events."""
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_%s_traffic.json" % workload)))
     if not found:
         return
     with open(found[-1]) as f:
         prof = json.load(f)
+    roof = result["roofline"]
+    roof["timing_source"] = "HIP events on the context's stream, this run"
+    src = os.path.relpath(found[-1], ROOT)
+
+    def bare(name):  # exact kernel, template arguments included ("void orcd::string_bytes_kernel<true, true>")
+        return name.replace("void ", "").replace("orcd::", "").strip()
     for name, k in prof.get("kernels", {}).items():
-        # exact kernel, template arguments included ("void orcd::string_bytes_kernel<true, true>")
-        bare = name.replace("void ", "").replace("orcd::", "").strip()
-        if bare == kernel and "hbm_bytes_per_launch" in k:
-            result["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
-            result["roofline"]["traffic_source"] = os.path.relpath(found[-1], ROOT)
-            return
+        if bare(name) == kernel and "hbm_bytes_per_launch" in k:
+            roof["traffic"] = k["hbm_bytes_per_launch"]
+            roof["traffic_source"] = src + " (PMC passes; bytes only, no timing)"
+    for name, ns in prof.get("avg_duration_ns", {}).items():
+        if bare(name) == kernel and ns > 0:
+            roof["avg_launch_ms_profiles"] = round(ns / 1e6, 4)
+            roof["frac_profiles"] = round(roof["algorithmic_bytes_per_launch"] / (ns * 1e-9) / 1e9 / HBM_PEAK_GBPS, 4)
+            roof["frac_profiles_source"] = src.replace("_traffic.json", "_kernel_stats.csv") + \
+                " (rocprofv3 --kernel-trace --stats of the same command, the builder's box)"
+    if "unprofiled_same_lease" in prof:
+        roof["profiles_unprofiled_same_lease"] = prof["unprofiled_same_lease"]
 
 
 def bench_strings(args, rank, world, local_rank, dist, desc, torch, np):
@@ -347,6 +367,9 @@ def bench_strings(args, rank, world, local_rank, dist, desc, torch, np):
 
     for _ in range(args.warmup):
         step()
+    ctx.synchronize()
+    offsets.zero_()   # the checks below see what the timed steps wrote, not the warm-up
+    out.zero_()
     barrier()
     phase_ms = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0}
     t0 = time.perf_counter()
@@ -621,6 +644,9 @@ def bench_boolean(args, rank, world, local_rank, dist, desc, torch, np):
 
     for _ in range(args.warmup):
         step()
+    ctx.synchronize()
+    out.zero_()   # the check below sees what the timed steps wrote, not the warm-up
+    ones[0] = -1
     barrier()
     phase_ms = {1: 0.0, 2: 0.0, 3: 0.0}
     t0 = time.perf_counter()

@@ -19,8 +19,15 @@ else
   LONG="bench.py --workload $WL --steps 10 --warmup 2 --no-cpu-baseline --headline-only"
   SHORT="bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --headline-only"
 fi
+# the same command without the profiler, in this lease: tells the box from the tracer when the
+# trace's durations are compared with another run's HIP events
+UNPROF=none
+if [ "$WL" = "$NAME" ]; then
+  timeout -k 10 300 python3 $LONG > $O/unprofiled.json 2> $O/unprofiled.err
+  UNPROF=$O/unprofiled.json
+fi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $LONG > $O/trace.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $SHORT > $O/fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $SHORT > $O/write.log 2>&1
-python3 bench_util/summarize_profile.py $O/trace $O/fetch $O/write $R/gpurun_out/round${ROUND}_${NAME} $NAME > $O/summary.log 2>&1
+python3 bench_util/summarize_profile.py $O/trace $O/fetch $O/write $R/gpurun_out/round${ROUND}_${NAME} $NAME $UNPROF > $O/summary.log 2>&1
 tail -2 $O/trace.log

@@ -1,9 +1,11 @@
 """Condenses rocprofv3 output directories into the summaries kept under profiles/.
 
-    python bench_util/summarize_profile.py <trace_dir> <fetch_dir> <write_dir> <out_prefix> <workload>
+    python bench_util/summarize_profile.py <trace_dir> <fetch_dir> <write_dir> <out_prefix> <workload> [<unprofiled.json>]
 
 trace_dir: `rocprofv3 --kernel-trace --stats --output-format csv` of bench.py;
 fetch_dir / write_dir: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the same command.
+unprofiled.json (optional): the JSON line of the same bench command run without the profiler in
+the same lease; its event timings are kept as "unprofiled_same_lease".
 Writes <out_prefix>_kernel_stats.csv (the decoder's kernels only) and <out_prefix>_traffic.json.
 
 Counter units and the gfx950 correction: rocprofv3 reports FETCH_SIZE and WRITE_SIZE in units of
@@ -66,6 +68,14 @@ def main():
         t["hbm_bytes_per_launch"] = fetch + write
     durations = {r["Name"].split("(")[0]: float(r["AverageNs"]) for r in rows}
     out = {"workload": workload, "kernels": traffic, "avg_duration_ns": durations}
+    if len(sys.argv) > 6 and os.path.exists(sys.argv[6]):
+        with open(sys.argv[6]) as f:
+            line = [ln for ln in f.read().splitlines() if ln.startswith("{")][-1]
+        b = json.loads(line)
+        out["unprofiled_same_lease"] = {
+            "kernel": b["roofline"]["kernel"], "avg_launch_ms": b["roofline"]["avg_launch_ms"],
+            "frac": b["roofline"]["frac"], "ms_per_step": b["ms_per_step"], "steps": b["steps"],
+            "note": "bench.py without rocprofv3, HIP events, same box and lease as the trace"}
     with open(prefix + "_traffic.json", "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))

@@ -831,7 +831,7 @@ int attempt_planned(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
     t.n_runs = 0;
     t.num_values = num_values;
     t.is_signed = is_signed;
-    HIP_TRY(c, launch_rlev2_values(c->stream, t, d_out, flag));
+    HIP_TRY(c, launch_rlev2_planned_values(c->stream, t, d_out, flag));
     mark(c, 3);
     const uint32_t stamp = next_stamp(c);
     HIP_TRY(c, launch_spec_publish(c->stream, flag, c->h_totals, stamp));

@@ -200,6 +200,10 @@ hipError_t launch_rlev2_resync(hipStream_t st, const uint8_t *stream, uint64_t l
 // abort_flag (nullable): a device word; when it is not zero as the kernel starts, nothing is decoded
 hipError_t launch_rlev2_values(hipStream_t st, const Rlev2Table &t, int64_t *out,
                                const uint32_t *abort_flag = nullptr);
+// The same behind a plan of the column: every window of t.group_run is one run (t.runs and
+// t.group_first are not looked at).
+hipError_t launch_rlev2_planned_values(hipStream_t st, const Rlev2Table &t, int64_t *out,
+                                       const uint32_t *abort_flag);
 // The run of every window for the column whose windows of 512 values are one run of 512 values
 // each (any kind), equally many of them between two entry points (see rlev2_regular_plan_kernel):
 // group_run[0 .. n_win), or *flag raised when the column is not like that.

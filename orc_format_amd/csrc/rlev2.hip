@@ -1184,6 +1184,54 @@ __device__ __forceinline__ void delta_window(const W &wv, int64_t *wout, uint32_
     }
 }
 
+// The same for a window that is all one run of 512 values (the bulk of a sorted column): the run
+// starts with the window, so lane i of step j owns the run's values 128 j + 2 i and + 1, only
+// values 0 and 1 (lane 0 of step 0) lack a packed delta, and nothing has to be masked.  What the
+// general form computes per value is computed per step here: the running value -- first value plus
+// or minus the deltas of the steps before -- is a scalar, a lane adds its step's inclusive sum to
+// it for its second value and takes its second delta off again for the first.
+// PAIRED: fields of at most 16 bits; a lane's two fields lie side by side and come out of one
+// 64-bit word.  bit0: LDS bit position of the run's packed field 0.
+template <bool PAIRED, bool WIDE, typename SUM, bool NEG, class W>
+__device__ __forceinline__ void delta_window_full(const W &wv, int64_t *wout, uint32_t w, uint64_t base,
+                                                  uint64_t delta_base, uint32_t bit0) {
+    const uint32_t lane = (uint32_t)wv.lane;
+    uint64_t run = base + delta_base;  // (wave-uniform) value 1, then the last value of the step before
+    const uint32_t bit = bit0 + (2u * lane - 2u) * w;  // lane 0, step 0: no field, see below
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t bA = bit + (128u * j) * w;
+        if (j == 0 && lane == 0) bA = bit0;  // (any place inside the slice)
+        SUM m0, m1;
+        if (PAIRED) {
+            const uint32_t d = bA >> 5, sh = bA & 31;
+            const uint64_t x = ((uint64_t)wv.lds[d] << 32) | wv.lds[d + 1];
+            const uint32_t top = (uint32_t)((x << sh) >> 32);
+            m0 = (SUM)(top >> (32 - w));
+            m1 = (SUM)((top << w) >> (32 - w));
+        } else if (!WIDE) {
+            m0 = (SUM)lds_bits32(wv.lds, bA, w);
+            m1 = (SUM)lds_bits32(wv.lds, bA + w, w);
+        } else {
+            m0 = (SUM)lds_bits64(wv.lds, bA, w);
+            m1 = (SUM)lds_bits64(wv.lds, bA + w, w);
+        }
+        if (j == 0 && lane == 0) {
+            m0 = 0;
+            m1 = 0;
+        }
+        const SUM incl = wave_scan_dpp((SUM)(m0 + m1));
+        uint64_t v1 = NEG ? run - incl : run + incl;
+        uint64_t v0 = NEG ? v1 + m1 : v1 - m1;
+        if (j == 0 && lane == 0) v0 = base;
+        SUM total;
+        if (sizeof(SUM) == 4) total = (SUM)readlane32((uint32_t)incl, 63);
+        else total = (SUM)readlane64((uint64_t)incl, 63);
+        run = NEG ? run - total : run + total;
+        store_window_pair<true>(wv, wout, 128u * j + 2u * lane, v0, v1, 0, WINDOW);
+    }
+}
+
 // ShortRepeat (step 0) and Delta without packed deltas: base + i * step.
 template <bool FULL, class W>
 __device__ __forceinline__ void linear_window(const W &wv, int64_t *wout, uint64_t base,
@@ -1252,7 +1300,21 @@ __device__ __forceinline__ void decode_single_run(const W &wv, uint64_t desc, ui
         } else if (kind == KIND_DELTA && w != 0) {
             const bool neg = desc_delta_neg(desc) != 0;
             const uint32_t bit_lane = bit0 + (uint32_t)(idx0 - 2) * w;
-            if (w <= 23) {
+            if (full && rlen == WINDOW) {  // (a full window of a run of 512 values: the run starts with it)
+                if (w <= 16) {
+                    if (neg) delta_window_full<true, false, uint32_t, true>(wv, wout, w, base, aux, bit0);
+                    else delta_window_full<true, false, uint32_t, false>(wv, wout, w, base, aux, bit0);
+                } else if (w <= 23) {
+                    if (neg) delta_window_full<false, false, uint32_t, true>(wv, wout, w, base, aux, bit0);
+                    else delta_window_full<false, false, uint32_t, false>(wv, wout, w, base, aux, bit0);
+                } else if (w <= 32) {
+                    if (neg) delta_window_full<false, false, uint64_t, true>(wv, wout, w, base, aux, bit0);
+                    else delta_window_full<false, false, uint64_t, false>(wv, wout, w, base, aux, bit0);
+                } else {
+                    if (neg) delta_window_full<false, true, uint64_t, true>(wv, wout, w, base, aux, bit0);
+                    else delta_window_full<false, true, uint64_t, false>(wv, wout, w, base, aux, bit0);
+                }
+            } else if (w <= 23) {
                 if (full) delta_window<true, false, uint32_t>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
                 else delta_window<false, false, uint32_t>(wv, wout, w, neg, base, aux, bit_lane, idx0, lo_rel, hi_rel, carry);
             } else if (w <= 32) {
@@ -1930,6 +1992,151 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
 }
 
 // ---------------------------------------------------------------------------------------------
+// K3 behind a plan of the column (rlev2_regular_plan_kernel): every window is one run, and its entry
+// in group_run says everything about it.  The same expansion as rlev2_values_kernel makes of a
+// single-run window, in a kernel of its own: without the code for windows that several runs share
+// it keeps clear of the register limit that eight wavefronts per SIMD set, and a wavefront can
+// take two neighbouring windows at once (TWO) -- both entries are fetched together, then the
+// stream bytes of both, each into its half of the wavefront's LDS slice, and only then is either
+// expanded, so that the two dependent memory hops of a window are paid once per pair.  Windows that
+// are not plain (a last window cut short, fields wider than 32 bits, PatchedBase) go one after the
+// other through decode_single_run.
+// ---------------------------------------------------------------------------------------------
+
+constexpr uint32_t HALF_STAGE_BYTES = STAGE_BYTES / 2;  // 2112: a run of 512 fields of 32 bits + skew
+
+// Is this entry a whole window of one Direct or Delta run of 512 values whose packed bytes fit half
+// a slice?  (all arguments wave-uniform)
+__device__ __forceinline__ bool plain_full_window(uint64_t desc, uint64_t out_off, uint64_t g,
+                                                  uint64_t num_values) {
+    const uint32_t kind = desc_kind(desc), w = desc_width(desc);
+    return (desc & DESC_SINGLE) && out_off == (g << WINDOW_SHIFT) && desc_len(desc) == WINDOW &&
+           ((g + 1) << WINDOW_SHIFT) <= num_values && w >= 1 && w <= 32 &&
+           (kind == KIND_DIRECT || kind == KIND_DELTA);
+}
+
+// The packed bytes of such a window: how many, from where.
+__device__ __forceinline__ uint32_t plain_window_bytes(uint64_t desc) {
+    const uint32_t fields = desc_kind(desc) == KIND_DELTA ? WINDOW - 2 : WINDOW;
+    return (fields * desc_width(desc) + 7) >> 3;
+}
+
+// Expands a plain full window whose packed bytes are staged at LDS bit bit0 of wv.lds.
+template <class W>
+__device__ __forceinline__ void expand_plain_window(const W &wv, int64_t *wout, uint64_t desc, uint64_t base,
+                                                    uint64_t aux, uint32_t bit0) {
+    const uint32_t w = desc_width(desc);
+    if (desc_kind(desc) == KIND_DIRECT) {
+        direct_window<true, false>(wv, wout, w, wv.is_signed != 0, 0, bit0 + 2u * (uint32_t)wv.lane * w, 0, WINDOW);
+    } else {
+        const bool neg = desc_delta_neg(desc) != 0;
+        if (w <= 16) {
+            if (neg) delta_window_full<true, false, uint32_t, true>(wv, wout, w, base, aux, bit0);
+            else delta_window_full<true, false, uint32_t, false>(wv, wout, w, base, aux, bit0);
+        } else if (w <= 23) {
+            if (neg) delta_window_full<false, false, uint32_t, true>(wv, wout, w, base, aux, bit0);
+            else delta_window_full<false, false, uint32_t, false>(wv, wout, w, base, aux, bit0);
+        } else {
+            if (neg) delta_window_full<false, false, uint64_t, true>(wv, wout, w, base, aux, bit0);
+            else delta_window_full<false, false, uint64_t, false>(wv, wout, w, base, aux, bit0);
+        }
+    }
+}
+
+template <bool TWO>
+__global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_planned_values_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const RunEntry *__restrict__ group_run, uint32_t n_groups,
+    uint64_t num_values, int is_signed, int64_t *__restrict__ out, const uint32_t *__restrict__ flags) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[VAL_WAVES][STAGE_WORDS];
+    __shared__ uint32_t patch_tab[VAL_WAVES][PATCH_TAB_WORDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t wg = blockIdx.x;  // XCD-contiguous remap, as in rlev2_values_kernel
+    {
+        const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = wg % 8;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
+    }
+    const uint32_t g = (wg * VAL_WAVES + wave) * (TWO ? 2 : 1);
+    if (g >= n_groups) return;  // whole wavefront; no workgroup barrier below
+    // a raised flag: the plan did not hold and the entries are not all written (a plain load: the
+    // word is final before this kernel starts)
+    const uint32_t aborted = flags ? *flags : 0u;
+    WaveOf<MODE_VALUES> wv;
+    wv.s = s;
+    wv.lds = stage[wave];
+    wv.marks = nullptr;
+    wv.patch_tab = patch_tab[wave];
+    wv.out = out;
+    wv.num_values = num_values;
+    wv.len = len;
+    wv.lane = threadIdx.x & 63;
+    wv.is_signed = is_signed;
+    wv.out_aligned = (((uintptr_t)out) & 15) == 0;
+    wv.acc = 0;
+    wv.saw_patched = 0;
+    const bool two = TWO && g + 1 < n_groups;
+    const RunEntry *ea = group_run + g, *eb = group_run + (two ? g + 1 : g);  // wave-uniform addresses
+    const uint64_t da = readfirstlane64(ea->desc), oa = readfirstlane64(ea->out_off);
+    const uint64_t ba = readfirstlane64(ea->base), xa = readfirstlane64(ea->aux);
+    const uint64_t db = readfirstlane64(eb->desc), ob = readfirstlane64(eb->out_off);
+    const uint64_t bb = readfirstlane64(eb->base), xb = readfirstlane64(eb->aux);
+    if (__builtin_amdgcn_readfirstlane(aborted)) return;
+    const bool plain_a = wv.out_aligned && plain_full_window(da, oa, g, num_values);
+    const bool plain_b = two && wv.out_aligned && plain_full_window(db, ob, (uint64_t)g + 1, num_values);
+    // the packed bytes of the plain ones, all loads first
+    uint4 va[3], vb[3];
+    uint32_t na = 0, nb = 0, ska = 0, skb = 0;
+    if (plain_a) {
+        const uint64_t p0 = desc_payload(da);
+        uint64_t p1 = p0 + plain_window_bytes(da);
+        if (p1 > len) p1 = len;  // (the plan has checked every run against the stream's length)
+        ska = (uint32_t)((uintptr_t)(s + p0) & 15);
+        na = p1 > p0 ? (uint32_t)((p1 - p0 + ska + 15) >> 4) : 0;
+        const uint4 *src = (const uint4 *)(s + p0 - ska);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (64u * i + wv.lane < na) va[i] = src[64u * i + wv.lane];
+    }
+    if (plain_b) {
+        const uint64_t p0 = desc_payload(db);
+        uint64_t p1 = p0 + plain_window_bytes(db);
+        if (p1 > len) p1 = len;
+        skb = (uint32_t)((uintptr_t)(s + p0) & 15);
+        nb = p1 > p0 ? (uint32_t)((p1 - p0 + skb + 15) >> 4) : 0;
+        const uint4 *src = (const uint4 *)(s + p0 - skb);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (64u * i + wv.lane < nb) vb[i] = src[64u * i + wv.lane];
+    }
+    auto put = [&](const uint4 (&v)[3], uint32_t n, uint32_t *lds) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (64u * i + wv.lane < n) {
+                uint4 x = v[i];
+                x.x = __builtin_bswap32(x.x);
+                x.y = __builtin_bswap32(x.y);
+                x.z = __builtin_bswap32(x.z);
+                x.w = __builtin_bswap32(x.w);
+                ((uint4 *)lds)[64u * i + wv.lane] = x;
+            }
+    };
+    uint32_t *lds_b = wv.lds + HALF_STAGE_BYTES / 4;
+    if (plain_a) put(va, na, wv.lds);
+    if (plain_b) put(vb, nb, lds_b);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (plain_a) expand_plain_window(wv, out + ((uint64_t)g << WINDOW_SHIFT), da, ba, xa, ska * 8);
+    if (plain_b) {
+        WaveOf<MODE_VALUES> wb = wv;
+        wb.lds = lds_b;
+        expand_plain_window(wb, out + (((uint64_t)g + 1) << WINDOW_SHIFT), db, bb, xb, skb * 8);
+    }
+    // whatever is not plain, the general way (it stages for itself, after the plain ones are done
+    // with the slice)
+    if (!plain_a && (da & DESC_SINGLE)) decode_single_run(wv, da, oa, ba, xa);
+    if (two && !plain_b && (db & DESC_SINGLE)) decode_single_run(wv, db, ob, bb, xb);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3 without K1/K2 for the regular column: every window of 512 values is one Direct run of 512
 // values, and the runs between two entry points all have one size.  Then nothing about a run has to
 // be looked up: the segment of window g is g / R (R runs per segment), the run's size S is the
@@ -2447,6 +2654,26 @@ hipError_t launch_rlev2_resync(hipStream_t st, const uint8_t *stream, uint64_t l
                                uint64_t spacing, uint32_t n_entries, uint64_t *entries) {
     if (n_entries == 0) return hipSuccess;
     rlev2_resync_kernel<<<(n_entries + 3) / 4, 256, 0, st>>>(stream, len, is_signed, spacing, n_entries, entries);
+    return hipGetLastError();
+}
+
+hipError_t launch_rlev2_planned_values(hipStream_t st, const Rlev2Table &t, int64_t *out,
+                                       const uint32_t *abort_flag) {
+    if (t.n_groups == 0) return hipSuccess;
+    static const int variant = [] {
+        const char *e = getenv("ORCD_EXP_PLANNED");
+        return e ? atoi(e) : 1;
+    }();
+    if (variant == 0) return launch_values_mode<MODE_VALUES>(st, t, out, nullptr, const_cast<uint32_t *>(abort_flag));
+    if (variant == 1) {
+        const uint32_t blocks = (t.n_groups + VAL_WAVES - 1) / VAL_WAVES;
+        rlev2_planned_values_kernel<false><<<blocks, VAL_WAVES * 64, 0, st>>>(t.stream, t.len, t.group_run, t.n_groups,
+                                                                             t.num_values, t.is_signed, out, abort_flag);
+    } else {
+        const uint32_t blocks = ((t.n_groups + 1) / 2 + VAL_WAVES - 1) / VAL_WAVES;
+        rlev2_planned_values_kernel<true><<<blocks, VAL_WAVES * 64, 0, st>>>(t.stream, t.len, t.group_run, t.n_groups,
+                                                                            t.num_values, t.is_signed, out, abort_flag);
+    }
     return hipGetLastError();
 }
 
