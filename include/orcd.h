@@ -114,8 +114,10 @@ float orcd_ctx_phase_ms(orcd_ctx *ctx, int phase);
  * Direct run, with equally many equal-sized runs between two entry points, is expanded by a single
  * launch that checks each run header as it goes) or ORCD_PATH_PLANNED (a column whose every 512
  * values are one run of any kind -- full Delta runs of sorted keys, say -- with equally many runs
- * between two entry points: one launch finds and verifies every run header, the value expansion
- * follows it without prefix sums or a wait in between).  The library tries the one that worked
+ * between two entry points, or a known number of values (orcd_rlev2_decode_groups): every run
+ * header is found by interpolation between the entry points and proven by its links to its
+ * neighbours, in the launch that expands the values or in one ahead of it, without prefix sums or
+ * a wait in between).  The library tries the one that worked
  * for the context's last column first, then the other, and falls back to the general path.
  * The results are the same either way; this is for benchmarks and profiles. */
 enum { ORCD_PATH_GENERAL = 0, ORCD_PATH_STRIDED = 1, ORCD_PATH_PLANNED = 2 };
@@ -140,6 +142,24 @@ const char *orcd_ctx_last_hip_error(orcd_ctx *ctx);
 int orcd_rlev2_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_values,
                       const uint64_t *entry_points, size_t n_entries, int64_t *out,
                       unsigned flags);
+
+/* orcd_rlev2_decode for a stream whose entry points are the ROW_INDEX positions of a file, one per
+ * row group (src/proto.rs:89-99, RowIndexEntry.positions: for an integer stream the byte offset of
+ * a run header and the number of that run's values to skip; the crate drops the index,
+ * src/read/mod.rs:136).  `values_per_group`: the stream holds that many values per row group --
+ * the file's row index stride for a column without nulls -- and entry point k is the header of
+ * the run that holds value k * values_per_group.  The writers do not cut a run where a row group
+ * ends, so with the default stride of 10 000 a group starts 272, 32, 304 ... values into a run of
+ * 512 and the segments between entry points hold 19 or 20 runs; the values-to-skip say exactly
+ * that and are implied by values_per_group when every run holds 512 values.  The number only lets
+ * the decoder try the paths that need no header scan (orcd_ctx_last_path) on such a column; every
+ * header and entry point is still checked, and a stream that is not like that -- or a wrong
+ * number -- is decoded the general way with the same result.  0: exactly orcd_rlev2_decode.
+ * orcd_column_values_per_group gives the number for a stream of a column handle (0 when the
+ * positions of the index are not of that shape). */
+int orcd_rlev2_decode_groups(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_values,
+                             const uint64_t *entry_points, size_t n_entries, uint64_t values_per_group,
+                             int64_t *out, unsigned flags);
 
 /* Compression chunks of a zlib file inflated on the device, a workgroup per chunk: what the crate's
  * Decompressor does one chunk at a time on the host (src/read/decompress/mod.rs:60-80: a chunk
@@ -390,6 +410,11 @@ int orcd_file_read_at(orcd_file *file, uint64_t offset, uint64_t len, uint8_t *d
  * offsets for stream `kind`. */
 int orcd_column_entry_points(orcd_file *file, orcd_column *column, int kind,
                              const uint64_t **entries, size_t *n_entries);
+/* For the same stream: the `values_per_group` of orcd_rlev2_decode_groups -- the file's row index
+ * stride when the index holds one position per row group for the stream and every position's
+ * values-to-skip (the second number of an RLE v2 position, src/proto.rs:89-99) is what runs of 512
+ * values throughout make it, (k * stride) mod 512 -- else 0. */
+uint64_t orcd_column_values_per_group(orcd_file *file, orcd_column *column, int kind);
 
 /* ---- null scatter and whole columns ------------------------------------------------------------ */
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     "orcd_ctx_last_hip_error": (C.c_char_p, [P]),
     "orcd_ctx_last_path": (C.c_int, [P]),
     "orcd_rlev2_decode": (C.c_int, [P, P, SZ, SZ, U64P, SZ, P, C.c_uint]),
+    "orcd_rlev2_decode_groups": (C.c_int, [P, P, SZ, SZ, U64P, SZ, C.c_uint64, P, C.c_uint]),
     "orcd_rlev1_decode": (C.c_int, [P, P, SZ, SZ, U64P, SZ, P, C.c_uint]),
     "orcd_inflate_chunks": (C.c_int, [P, P, SZ, P, SZ, P, SZ, P, C.c_uint]),
     "orcd_rlev2_decode_noalloc": (C.c_int, [P, P, SZ, SZ, U64P, SZ, P, C.c_uint]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "orcd_column_encoding": (C.c_int, [P, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "orcd_column_number_of_rows": (C.c_uint64, [P]),
     "orcd_column_entry_points": (C.c_int, [P, P, C.c_int, C.POINTER(P), C.POINTER(SZ)]),
+    "orcd_column_values_per_group": (C.c_uint64, [P, P, C.c_int]),
     "orcd_stripe_column_open": (C.c_int, [P, SZ, P, C.c_uint32, C.POINTER(P)]),
     "orcd_column_region": (C.c_int, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "orcd_column_stream_range": (C.c_int, [P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -129,13 +129,20 @@ class Context:
         return int(self._lib.orcd_ctx_last_path(self._h))
 
     # ---- host-buffer calls ------------------------------------------------------------------
-    def rlev2(self, stream, num_values, signed, entry_points=None):
+    def rlev2(self, stream, num_values, signed, entry_points=None, values_per_group=0):
+        """orcd_rlev2_decode, or with values_per_group orcd_rlev2_decode_groups: the entry points
+        are one per row group of that many values (ROW_INDEX positions of a file)."""
         s = _host_u8(stream)
         e, ne = _entries(entry_points)
         out = np.empty(num_values, dtype=np.int64)
-        rc = self._lib.orcd_rlev2_decode(self._h, s.ctypes.data, s.size, num_values,
-                                         e.ctypes.data if ne else None, ne, out.ctypes.data,
-                                         N.SIGNED if signed else 0)
+        if values_per_group:
+            rc = self._lib.orcd_rlev2_decode_groups(self._h, s.ctypes.data, s.size, num_values,
+                                                    e.ctypes.data if ne else None, ne, int(values_per_group),
+                                                    out.ctypes.data, N.SIGNED if signed else 0)
+        else:
+            rc = self._lib.orcd_rlev2_decode(self._h, s.ctypes.data, s.size, num_values,
+                                             e.ctypes.data if ne else None, ne, out.ctypes.data,
+                                             N.SIGNED if signed else 0)
         check(rc, self._h)
         return out
 
@@ -360,10 +367,15 @@ class Context:
 
     # ---- device-pointer calls (raw addresses) -------------------------------------------------
     def rlev2_device(self, stream_ptr, length, num_values, signed, out_ptr, entries_ptr=0,
-                     n_entries=0):
-        rc = self._lib.orcd_rlev2_decode(self._h, stream_ptr, length, num_values,
-                                         entries_ptr or None, n_entries, out_ptr,
-                                         (N.SIGNED if signed else 0) | N.IN_DEVICE | N.OUT_DEVICE)
+                     n_entries=0, values_per_group=0):
+        flags = (N.SIGNED if signed else 0) | N.IN_DEVICE | N.OUT_DEVICE
+        if values_per_group:
+            rc = self._lib.orcd_rlev2_decode_groups(self._h, stream_ptr, length, num_values,
+                                                    entries_ptr or None, n_entries, int(values_per_group),
+                                                    out_ptr, flags)
+        else:
+            rc = self._lib.orcd_rlev2_decode(self._h, stream_ptr, length, num_values,
+                                             entries_ptr or None, n_entries, out_ptr, flags)
         check(rc, self._h)
 
     def rlev2_device_noalloc(self, stream_ptr, length, num_values, signed, out_ptr, entries_ptr=0,

@@ -734,6 +734,7 @@ int rlev2_table_with(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t nu
 // attempt succeeds.  (On a column of 10^9 values a failed attempt measured 0.16 to 0.22 ms: two
 // million wavefronts that each fetch an entry point and a header before they can tell.)
 constexpr size_t SPEC_MIN_VALUES = 8 * WINDOW;
+constexpr size_t SELFPLAN_MAX_BYTES_PER_WINDOW = 832;
 constexpr uint32_t SPEC_BACKOFF = 16;
 
 // Whether a call is for the speculative paths at all, and the count-down after failed attempts.
@@ -790,7 +791,7 @@ int spec_verdict(orcd_ctx *c, uint32_t stamp, bool *done) {
 // flag_word (nullable): the device word to use instead of the context's own, zero on entry.
 int attempt_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
                     const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done,
-                    uint32_t *flag_word = nullptr) {
+                    uint32_t *flag_word = nullptr, uint32_t stride_vals = 0) {
     *done = false;
     if (((uintptr_t)d_out) & 15) return ORCD_OK;
     const uint64_t n_win = (num_values + WINDOW - 1) >> WINDOW_SHIFT;
@@ -800,7 +801,7 @@ int attempt_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
     const uint32_t stamp = next_stamp(c);
     HIP_TRY(c, launch_rlev2_strided_values(c->stream, d_stream, len, n_entries ? d_entries : nullptr,
                                            (uint32_t)n_seg, (uint32_t)n_win, num_values, is_signed, d_out,
-                                           flag, c->h_totals, stamp));
+                                           flag, c->h_totals, stamp, stride_vals));
     mark(c, 3);  // (phases 1 and 2, header count and run table, did not run)
     return spec_verdict(c, stamp, done);
 }
@@ -808,13 +809,41 @@ int attempt_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
 // The column of full runs of any kind (see rlev2_regular_plan_kernel): the plan of the windows and
 // the value kernel behind it in one go, no prefix sums and no wait in between.
 int attempt_planned(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
-                    const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done) {
+                    const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out, bool *done,
+                    uint32_t stride_vals = 0) {
     *done = false;
     const uint64_t n_win = (num_values + WINDOW - 1) >> WINDOW_SHIFT;
     uint32_t r_lo, r_hi;
-    if (n_entries < 2 || !rlev2_regular_plan_shape((uint32_t)n_entries, (uint32_t)n_win, &r_lo, &r_hi)) return ORCD_OK;
+    const bool even = rlev2_regular_plan_shape((uint32_t)n_entries, (uint32_t)n_win, &r_lo, &r_hi);
+    if (n_entries < 2 || (!even && !stride_vals)) return ORCD_OK;
     uint32_t *flag;
     ORCD_TRY(spec_flag(c, &flag));
+    // Plan and expansion in one launch, or the plan as a pass of its own ahead of the expansion?
+    // The first spares the pass (0.12 ms per 10^9 values) and costs every window the search for
+    // its header and the header's decoding (0.09 to 0.16 ms), which weighs the more the longer the
+    // window's bytes take to arrive anyway: measured faster up to about 800 stream bytes per
+    // window (10-bit deltas: 1.69 against 1.74 ms), slower above (16-bit: 1.83 against 1.79).
+    // Segments of unequal run counts (stride_vals) are only for the first.
+    const bool dense = len / n_win <= SELFPLAN_MAX_BYTES_PER_WINDOW;
+    const bool selfplan = (stride_vals || dense || !even) && !(((uintptr_t)d_out) & 15) &&
+                          rlev2_selfplan_shape((uint32_t)n_entries, (uint32_t)n_win, stride_vals);
+    if (selfplan) {
+        void *seg_table;
+        ORCD_TRY(ensure(c, SLOT_GROUPS, rlev2_selfplan_table_bytes((uint32_t)n_entries), &seg_table));
+        HIP_TRY(c, launch_rlev2_selfplan_values(c->stream, d_stream, len, d_entries, (uint32_t)n_entries, (uint32_t)n_win,
+                                                stride_vals, num_values, is_signed, d_out, flag, seg_table));
+        mark(c, 3);
+        const uint32_t stamp = next_stamp(c);
+        HIP_TRY(c, launch_spec_publish(c->stream, flag, c->h_totals, stamp));
+        ORCD_TRY(spec_verdict(c, stamp, done));
+        if (*done) {
+            c->h_totals->error_seg = 1;  // (no word on whether the strided kernel would do: stay with this path)
+            return ORCD_OK;
+        }
+        // not a column of like runs a regular distance apart: the plan as a pass of its own copes
+        // with runs of any size (its lanes walk where their guesses miss)
+    }
+    if (stride_vals || !even) return ORCD_OK;  // (that pass wants equally many runs in every segment)
     void *group_runs;
     ORCD_TRY(ensure(c, SLOT_GROUP_RUNS, (size_t)(n_win + 1) * sizeof(RunEntry), &group_runs));
     HIP_TRY(c, launch_rlev2_regular_plan(c->stream, d_stream, len, d_entries, (uint32_t)n_entries, (uint32_t)n_win,
@@ -849,8 +878,10 @@ int try_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_val
 }
 
 int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,
-                 const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out) {
+                 const uint64_t *d_entries, size_t n_entries, int is_signed, int64_t *d_out,
+                 uint64_t stride_vals = 0) {
     c->last_path = ORCD_PATH_GENERAL;
+    if (stride_vals >= (1u << 23) || stride_vals < WINDOW) stride_vals = 0;  // (not a stride the paths below take)
     if (spec_gate(c, len, num_values, n_entries)) {
         // the way that worked last time first, then the other
         bool done = false;
@@ -859,9 +890,11 @@ int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_va
             const int way = attempt == 0 ? first
                                          : (first == ORCD_PATH_STRIDED ? ORCD_PATH_PLANNED : ORCD_PATH_STRIDED);
             if (way == ORCD_PATH_STRIDED)
-                ORCD_TRY(attempt_strided(c, d_stream, len, num_values, d_entries, n_entries, is_signed, d_out, &done));
+                ORCD_TRY(attempt_strided(c, d_stream, len, num_values, d_entries, n_entries, is_signed, d_out, &done,
+                                         nullptr, (uint32_t)stride_vals));
             else
-                ORCD_TRY(attempt_planned(c, d_stream, len, num_values, d_entries, n_entries, is_signed, d_out, &done));
+                ORCD_TRY(attempt_planned(c, d_stream, len, num_values, d_entries, n_entries, is_signed, d_out, &done,
+                                         (uint32_t)stride_vals));
             if (done) {
                 c->spec_pref = c->last_path = way;
                 // equal-sized Direct runs all through: the strided kernel needs no plan for such a
@@ -1162,6 +1195,32 @@ int orcd_rlev2_decode(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num
     }
     ORCD_TRY(rlev2_device(c, (const uint8_t *)d_stream, len, num_values, (const uint64_t *)d_entries,
                           n_entries, (flags & ORCD_SIGNED) ? 1 : 0, d_out));
+    if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, num_values * sizeof(int64_t)));
+    return ORCD_OK;
+} ORCD_CATCH
+
+int orcd_rlev2_decode_groups(orcd_ctx *c, const uint8_t *stream, size_t len, size_t num_values,
+                             const uint64_t *entry_points, size_t n_entries, uint64_t values_per_group,
+                             int64_t *out, unsigned flags) try {
+    if (!c || (len && !stream) || (num_values && !out) || (n_entries && !entry_points))
+        return ORCD_INVALID_ARGUMENT;
+    if (num_values == 0) return ORCD_OK;
+    DeviceGuard g(c->device);
+    reset_events(c);
+    const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
+    mark(c, 0);
+    const void *d_stream, *d_entries;
+    ORCD_TRY(stage_in(c, SLOT_IN_A, stream, len, in_dev, &d_stream));
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, entry_points, n_entries * sizeof(uint64_t),
+                      in_dev && !(flags & ORCD_ENTRIES_HOST), &d_entries));
+    int64_t *d_out = out;
+    if (!out_dev) {
+        void *p;
+        ORCD_TRY(ensure(c, SLOT_OUT_A, num_values * sizeof(int64_t), &p));
+        d_out = (int64_t *)p;
+    }
+    ORCD_TRY(rlev2_device(c, (const uint8_t *)d_stream, len, num_values, (const uint64_t *)d_entries,
+                          n_entries, (flags & ORCD_SIGNED) ? 1 : 0, d_out, values_per_group));
     if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, num_values * sizeof(int64_t)));
     return ORCD_OK;
 } ORCD_CATCH
@@ -2330,8 +2389,10 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
         ORCD_TRY(cs.get(ORCD_STREAM_DATA, &sb, &sl, &ent, &n_ent, n_values != 0));
         if (enc == ORCD_ENC_DIRECT)  // a file written as ORC 0.11: integer RLE version 1
             ORCD_TRY(orcd_rlev1_decode(c, sb, sl, n_values, ent, n_ent, (int64_t *)p.values, ORCD_SIGNED | io));
-        else
-            ORCD_TRY(orcd_rlev2_decode(c, sb, sl, n_values, ent, n_ent, (int64_t *)p.values, ORCD_SIGNED | io));
+        else  // (the index's values-to-skip, when they describe runs of 512 values: no header scan then)
+            ORCD_TRY(orcd_rlev2_decode_groups(c, sb, sl, n_values, ent, n_ent,
+                                              orcd_column_values_per_group(cs.file, col, ORCD_STREAM_DATA),
+                                              (int64_t *)p.values, ORCD_SIGNED | io));
         break;
     }
     case T_BOOLEAN: {  // deserialize_bool_array, deserialize.rs:84-104
@@ -2492,6 +2553,7 @@ struct StripeJob {
 // Streams up to this size share one set of launches -- and one wait for the header totals -- with
 // their peers (measured on a 26-column file: the larger the limit, the faster, up to here).
 constexpr uint64_t BATCH_STREAM_MAX = 64u << 20;
+constexpr uint64_t BATCH_REGULAR_MIN = 1u << 22;  // values from which a column of full runs goes alone
 
 // One batch of streams that lie in the stripe's device copy: slice offsets are relative to the
 // first byte any of them uses.
@@ -3000,6 +3062,9 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
             const uint64_t *ent;
             if (cs.get(ORCD_STREAM_DATA, &b, &l, &ent, &n_ent, true) != ORCD_OK) continue;  // reported per column below
             if (l > BATCH_STREAM_MAX) continue;
+            // a long column of full runs (the index says so) is better off by itself: no header scan
+            if ((*jobs[i]).n_values >= BATCH_REGULAR_MIN && orcd_column_values_per_group(file, (*jobs[i]).col, ORCD_STREAM_DATA))
+                continue;
             batch.add(i, b, l, (*jobs[i]).n_values, ent, n_ent);
             total += (*jobs[i]).n_values;
         }

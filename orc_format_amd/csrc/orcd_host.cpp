@@ -189,6 +189,11 @@ struct orcd_column {
     bool index_loaded = false;
     int index_status = ORCD_OK;  // what loading the ROW_INDEX entry points came to (kept: asked once)
     std::vector<uint64_t> entries[8];
+    // For the integer streams: how many values lie between two positions when entry k is the header
+    // of the run that holds the stream's value k * that many -- i.e. when the index holds one
+    // position per row group for the stream, none was dropped as a duplicate, and every position's
+    // values-to-skip is what runs of 512 values throughout would make it -- else 0.
+    uint64_t group_values[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -704,6 +709,15 @@ int load_entry_points(orcd_file *file, orcd_column *col) {
     uint64_t v;
     Cursor sub{nullptr, nullptr};
     std::vector<uint64_t> pos;
+    // The values-to-skip that follows the byte offset of an RLE v2 position (src/proto.rs:89-99) says
+    // where in its run a row group starts.  When every run holds 512 values -- the bulk of a long
+    // column -- row group k of a stream that has a value for every row starts at value k * stride,
+    // in run floor(k * stride / 512), (k * stride) mod 512 values in: an index whose skips are
+    // exactly that tells the decoder which window of 512 values each entry point is the first of.
+    const uint64_t stride = file->row_index_stride;
+    bool regular[8];
+    for (int k = 0; k < 8; k++) regular[k] = stride >= 512;
+    uint64_t group = 0;
     while (c.next(field, wire, v, sub)) {
         if (field != 1 || wire != 2) continue;  // RowIndexEntry
         pos.clear();
@@ -736,10 +750,20 @@ int load_entry_points(orcd_file *file, orcd_column *col) {
                     return ORCD_OK;
                 }
             }
+            const size_t before = e.size();
             if (e.empty() || off > e.back()) e.push_back(off);  // ascending, no duplicates
+            // (positions_of: an RLE v2 position ends with its values-to-skip)
+            const int n_pos = positions_of(type_kind, encoding, sl.kind) + (file->compression != 0 ? 1 : 0);
+            const bool rle = positions_of(type_kind, encoding, sl.kind) == POS_RLEV2 && type_kind != 1;
+            if (!rle || e.size() != before + 1 || e.size() != group + 1 ||
+                pos[sl.first + n_pos - 1] != (group * stride) % 512)
+                regular[sl.kind] = false;
         }
+        group++;
     }
     if (!c.ok) return ORCD_INVALID_PROTO;
+    for (const auto &sl : slots)
+        if (regular[sl.kind] && col->entries[sl.kind].size() == group && group >= 2) col->group_values[sl.kind] = stride;
     return ORCD_OK;
 }
 
@@ -1146,13 +1170,22 @@ int orcd_column_entry_points(orcd_file *f, orcd_column *col, int kind, const uin
     if (!f || !col || !entries || !n_entries || kind < 0 || kind >= 8) return ORCD_INVALID_ARGUMENT;
     if (!col->index_loaded) {
         col->index_status = load_entry_points(f, col);
-        if (col->index_status != ORCD_OK)
+        if (col->index_status != ORCD_OK) {
             for (auto &e : col->entries) e.clear();
+            for (auto &g : col->group_values) g = 0;
+        }
     }
     if (col->index_status != ORCD_OK) return col->index_status;
     *entries = col->entries[kind].data();
     *n_entries = col->entries[kind].size();
     return ORCD_OK;
 } ORCD_CATCH
+
+uint64_t orcd_column_values_per_group(orcd_file *f, orcd_column *col, int kind) try {
+    const uint64_t *e;
+    size_t n;
+    if (orcd_column_entry_points(f, col, kind, &e, &n) != ORCD_OK) return 0;
+    return col->group_values[kind];
+} catch (...) { return 0; }
 
 }  // extern "C"

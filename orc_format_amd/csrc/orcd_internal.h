@@ -210,6 +210,19 @@ hipError_t launch_rlev2_planned_values(hipStream_t st, const Rlev2Table &t, int6
 // rlev2_regular_plan_shape: whether the counts of windows and entry points allow such a column at
 // all, and the runs per segment they leave possible (the kernel picks among several).
 bool rlev2_regular_plan_shape(uint32_t n_seg, uint32_t n_win, uint32_t *r_lo, uint32_t *r_hi);
+// Plan and expansion in one launch (see rlev2_selfplan_values_kernel).  stride_vals: values between
+// two entry points (entry k is the header of the run that holds value k * stride_vals; any number
+// from 512 to 2^23), or 0: equally many runs in every segment, how many follows from the counts.
+// flag: three zeroed words; flag[0] is raised when the column is not like that.  seg_table:
+// rlev2_selfplan_table_bytes(n_seg) bytes of device memory.  rlev2_selfplan_shape says whether the
+// counts are for this path at all.
+hipError_t launch_rlev2_selfplan_values(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                        const uint64_t *entries, uint32_t n_seg, uint32_t n_win,
+                                        uint32_t stride_vals, uint64_t num_values, int is_signed, int64_t *out,
+                                        uint32_t *flag, void *seg_table);
+size_t rlev2_selfplan_table_bytes(uint32_t n_seg);
+bool rlev2_selfplan_shape(uint32_t n_seg, uint32_t n_win, uint32_t stride_vals);
+
 hipError_t launch_rlev2_regular_plan(hipStream_t st, const uint8_t *stream, uint64_t len,
                                      const uint64_t *entries, uint32_t n_seg, uint32_t n_win,
                                      uint64_t num_values, int is_signed, RunEntry *group_run,
@@ -224,7 +237,7 @@ hipError_t launch_spec_publish(hipStream_t st, uint32_t *flag, ScanTotals *host_
 hipError_t launch_rlev2_strided_values(hipStream_t st, const uint8_t *stream, uint64_t len,
                                        const uint64_t *entries, uint32_t n_seg, uint32_t n_win,
                                        uint64_t num_values, int is_signed, int64_t *out, uint32_t *flag,
-                                       ScanTotals *host_totals, uint32_t stamp);
+                                       ScanTotals *host_totals, uint32_t stamp, uint32_t stride_vals = 0);
 // The same expansion, reduced: group_sums[g] = saturating sum of the values of the runs that
 // start in the g-th window of 512 values (bit 2 of *flags is raised when a PatchedBase run was
 // met: its patches are not in the sums) ...

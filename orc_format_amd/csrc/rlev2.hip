@@ -814,14 +814,16 @@ struct Wave {
     mutable uint64_t acc;
     mutable uint32_t saw_patched;  // MODE_SUMS: a PatchedBase run was met (its patches are not summed)
 };
-template <int M>
+template <int M, bool S = false>
 struct WaveOf : Wave {
     static constexpr int MODE = M;
+    static constexpr bool SHORT = S;  // the kernel variant for columns of short runs
 };
 
 // Copies stream bytes [b0, b1) into the LDS slice; returns the stream offset that LDS byte 0
 // stands for (up to 15 bytes before b0; it may wrap below zero, only differences are used).
 // Reads whole aligned 16-byte chunks: each holds at least one byte of [b0, b1).
+template <bool ONE_BY_ONE = false>
 __device__ __forceinline__ uint64_t stage_bytes(const Wave &wv, uint64_t b0, uint64_t b1) {
     // Belt and braces: the header scan has validated every run against the stream length, but a
     // range that is out of the stream or larger than the slice is never loaded, whatever the
@@ -831,13 +833,37 @@ __device__ __forceinline__ uint64_t stage_bytes(const Wave &wv, uint64_t b0, uin
     const uint32_t skew = (uint32_t)((uintptr_t)(wv.s + b0) & 15);
     const uint4 *src = (const uint4 *)(wv.s + b0 - skew);
     const uint32_t n16 = (uint32_t)((b1 - b0 + skew + 15) >> 4);
-    for (uint32_t c = wv.lane; c < n16; c += 64) {
-        uint4 v = src[c];
+    auto put = [&](uint32_t c, uint4 v) {
         v.x = __builtin_bswap32(v.x);
         v.y = __builtin_bswap32(v.y);
         v.z = __builtin_bswap32(v.z);
         v.w = __builtin_bswap32(v.w);
         ((uint4 *)wv.lds)[c] = v;
+    };
+    // All loads go out before the first is waited for: a copy loop that writes each chunk to LDS
+    // before it asks for the next pays a memory round trip per 1 KiB, and a run of 512 values of 17
+    // bits is 1090 bytes.  Three chunks per lane cover 3 KiB; longer ranges (fields wider than 48
+    // bits) take the rest in a loop.
+    // (ONE_BY_ONE: the plain loop, for the kernel variant whose registers are better spent elsewhere
+    // and whose runs rarely reach 1 KiB)
+    if (ONE_BY_ONE) {
+        for (uint32_t c = wv.lane; c < n16; c += 64) put(c, src[c]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return b0 - skew;
+    }
+    const uint32_t c0 = (uint32_t)wv.lane, c1 = c0 + 64, c2 = c0 + 128;
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0;
+    if (c0 < n16) v0 = src[c0];
+    if (n16 > 64) {  // (wave-uniform)
+        if (c1 < n16) v1 = src[c1];
+        if (n16 > 128 && c2 < n16) v2 = src[c2];
+    }
+    if (c0 < n16) put(c0, v0);
+    if (n16 > 64) {
+        if (c1 < n16) put(c1, v1);
+        if (n16 > 128 && c2 < n16) put(c2, v2);
+        for (uint32_t c = c0 + 192; c < n16; c += 64) put(c, src[c]);
     }
     // LDS operations of one wavefront execute in order; this only keeps the compiler from
     // moving the reads below above the writes
@@ -1272,7 +1298,7 @@ __device__ __forceinline__ void decode_single_run(const W &wv, uint64_t desc, ui
             payload_range(kind, w, (uint32_t)(win_idx + (int32_t)lo_rel),
                           (uint32_t)(win_idx + (int32_t)hi_rel), b0, b1);
             if (b1 > b0) {
-                const uint64_t origin = stage_bytes(wv, desc_payload(desc) + b0, desc_payload(desc) + b1);
+                const uint64_t origin = stage_bytes<W::SHORT>(wv, desc_payload(desc) + b0, desc_payload(desc) + b1);
                 bit0 = (uint32_t)((desc_payload(desc) - origin) << 3);
             }
         }
@@ -1300,7 +1326,7 @@ __device__ __forceinline__ void decode_single_run(const W &wv, uint64_t desc, ui
         } else if (kind == KIND_DELTA && w != 0) {
             const bool neg = desc_delta_neg(desc) != 0;
             const uint32_t bit_lane = bit0 + (uint32_t)(idx0 - 2) * w;
-            if (full && rlen == WINDOW) {  // (a full window of a run of 512 values: the run starts with it)
+            if (!W::SHORT && full && rlen == WINDOW) {  // (a full window of a run of 512 values: the run starts with it)
                 if (w <= 16) {
                     if (neg) delta_window_full<true, false, uint32_t, true>(wv, wout, w, base, aux, bit0);
                     else delta_window_full<true, false, uint32_t, false>(wv, wout, w, base, aux, bit0);
@@ -1587,7 +1613,7 @@ __device__ __forceinline__ void short_expand(const W &wv, const ShortPlan &pl) {
             __builtin_amdgcn_wave_barrier();
             origin = pl.b0 - skew;
         } else if (pl.b1 > pl.b0) {
-            origin = stage_bytes(wv, pl.b0, pl.b1);
+            origin = stage_bytes<W::SHORT>(wv, pl.b0, pl.b1);
         }
         if (tail_staged) {
             // the last run's values from own_end on, out of the bytes just staged (before the
@@ -1628,7 +1654,7 @@ __device__ __forceinline__ void short_expand(const W &wv, const ShortPlan &pl) {
         if (t_kind != KIND_DELTA) {
             const uint64_t f0 = t_kind == KIND_DIRECT ? ((uint64_t)first * t_w) >> 3 : 0u;
             const uint64_t f1 = t_kind == KIND_DIRECT ? ((uint64_t)end * t_w + 7) >> 3 : t_w >> 3;
-            const uint64_t origin = stage_bytes(wv, t_pay + f0, t_pay + f1);
+            const uint64_t origin = stage_bytes<W::SHORT>(wv, t_pay + f0, t_pay + f1);
             bit0 = (uint32_t)((t_pay - origin) << 3);
         }
         for (uint32_t idx = first + (uint32_t)lane; idx < end; idx += 64) {
@@ -1733,7 +1759,7 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
             const uint64_t span_b1 = readlane64(need_b1, k_hi);
             if (span_b1 - span_b0 + 15 <= STAGE_BYTES) {
                 use_lds = true;
-                lds_origin = stage_bytes(wv, span_b0, span_b1);
+                lds_origin = stage_bytes<W::SHORT>(wv, span_b0, span_b1);
             }
         }
 
@@ -1896,7 +1922,7 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
     // (the variant that writes the values of long runs is the one that meets whole PatchedBase runs)
     constexpr bool PATCH_AHEAD = MODE == MODE_VALUES && !SHORT;
     __shared__ uint32_t patch_tab[PATCH_AHEAD ? VAL_WAVES : 1][PATCH_AHEAD ? PATCH_TAB_WORDS : 1];
-    WaveOf<MODE> wv;
+    WaveOf<MODE, SHORT> wv;
     wv.s = s;
     wv.lds = stage[wave];
     wv.marks = marks[wave];
@@ -1995,55 +2021,14 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_ke
 // K3 behind a plan of the column (rlev2_regular_plan_kernel): every window is one run, and its entry
 // in group_run says everything about it.  The same expansion as rlev2_values_kernel makes of a
 // single-run window, in a kernel of its own: without the code for windows that several runs share
-// it keeps clear of the register limit that eight wavefronts per SIMD set, and a wavefront can
-// take two neighbouring windows at once (TWO) -- both entries are fetched together, then the
-// stream bytes of both, each into its half of the wavefront's LDS slice, and only then is either
-// expanded, so that the two dependent memory hops of a window are paid once per pair.  Windows that
-// are not plain (a last window cut short, fields wider than 32 bits, PatchedBase) go one after the
-// other through decode_single_run.
+// it keeps clear of the register limit that eight wavefronts per SIMD set (43 registers instead of
+// 64 and a few spilled; a sorted column of 16-bit deltas: 1.75 -> 1.64 ms per 10^9 values).
+// (A wavefront that takes two neighbouring windows -- both entries fetched together, then the
+// stream bytes of both, then the two expansions -- measured slower, 1.60 -> 1.66 ms: the loads of
+// twice the bytes take twice as long to come back, the memory system being what bounds the kernel,
+// and the second expansion waits behind the first.)
 // ---------------------------------------------------------------------------------------------
 
-constexpr uint32_t HALF_STAGE_BYTES = STAGE_BYTES / 2;  // 2112: a run of 512 fields of 32 bits + skew
-
-// Is this entry a whole window of one Direct or Delta run of 512 values whose packed bytes fit half
-// a slice?  (all arguments wave-uniform)
-__device__ __forceinline__ bool plain_full_window(uint64_t desc, uint64_t out_off, uint64_t g,
-                                                  uint64_t num_values) {
-    const uint32_t kind = desc_kind(desc), w = desc_width(desc);
-    return (desc & DESC_SINGLE) && out_off == (g << WINDOW_SHIFT) && desc_len(desc) == WINDOW &&
-           ((g + 1) << WINDOW_SHIFT) <= num_values && w >= 1 && w <= 32 &&
-           (kind == KIND_DIRECT || kind == KIND_DELTA);
-}
-
-// The packed bytes of such a window: how many, from where.
-__device__ __forceinline__ uint32_t plain_window_bytes(uint64_t desc) {
-    const uint32_t fields = desc_kind(desc) == KIND_DELTA ? WINDOW - 2 : WINDOW;
-    return (fields * desc_width(desc) + 7) >> 3;
-}
-
-// Expands a plain full window whose packed bytes are staged at LDS bit bit0 of wv.lds.
-template <class W>
-__device__ __forceinline__ void expand_plain_window(const W &wv, int64_t *wout, uint64_t desc, uint64_t base,
-                                                    uint64_t aux, uint32_t bit0) {
-    const uint32_t w = desc_width(desc);
-    if (desc_kind(desc) == KIND_DIRECT) {
-        direct_window<true, false>(wv, wout, w, wv.is_signed != 0, 0, bit0 + 2u * (uint32_t)wv.lane * w, 0, WINDOW);
-    } else {
-        const bool neg = desc_delta_neg(desc) != 0;
-        if (w <= 16) {
-            if (neg) delta_window_full<true, false, uint32_t, true>(wv, wout, w, base, aux, bit0);
-            else delta_window_full<true, false, uint32_t, false>(wv, wout, w, base, aux, bit0);
-        } else if (w <= 23) {
-            if (neg) delta_window_full<false, false, uint32_t, true>(wv, wout, w, base, aux, bit0);
-            else delta_window_full<false, false, uint32_t, false>(wv, wout, w, base, aux, bit0);
-        } else {
-            if (neg) delta_window_full<false, false, uint64_t, true>(wv, wout, w, base, aux, bit0);
-            else delta_window_full<false, false, uint64_t, false>(wv, wout, w, base, aux, bit0);
-        }
-    }
-}
-
-template <bool TWO>
 __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_planned_values_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const RunEntry *__restrict__ group_run, uint32_t n_groups,
     uint64_t num_values, int is_signed, int64_t *__restrict__ out, const uint32_t *__restrict__ flags) {
@@ -2055,10 +2040,10 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_planned_values_kernel
         const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = wg % 8;
         wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
     }
-    const uint32_t g = (wg * VAL_WAVES + wave) * (TWO ? 2 : 1);
+    const uint32_t g = wg * VAL_WAVES + wave;
     if (g >= n_groups) return;  // whole wavefront; no workgroup barrier below
     // a raised flag: the plan did not hold and the entries are not all written (a plain load: the
-    // word is final before this kernel starts)
+    // word is final before this kernel starts; looked at when the entry's loads are out as well)
     const uint32_t aborted = flags ? *flags : 0u;
     WaveOf<MODE_VALUES> wv;
     wv.s = s;
@@ -2073,67 +2058,11 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_planned_values_kernel
     wv.out_aligned = (((uintptr_t)out) & 15) == 0;
     wv.acc = 0;
     wv.saw_patched = 0;
-    const bool two = TWO && g + 1 < n_groups;
-    const RunEntry *ea = group_run + g, *eb = group_run + (two ? g + 1 : g);  // wave-uniform addresses
-    const uint64_t da = readfirstlane64(ea->desc), oa = readfirstlane64(ea->out_off);
-    const uint64_t ba = readfirstlane64(ea->base), xa = readfirstlane64(ea->aux);
-    const uint64_t db = readfirstlane64(eb->desc), ob = readfirstlane64(eb->out_off);
-    const uint64_t bb = readfirstlane64(eb->base), xb = readfirstlane64(eb->aux);
+    const RunEntry *e = group_run + g;  // wave-uniform address
+    const uint64_t desc = readfirstlane64(e->desc), out_off = readfirstlane64(e->out_off);
+    const uint64_t base = readfirstlane64(e->base), aux = readfirstlane64(e->aux);
     if (__builtin_amdgcn_readfirstlane(aborted)) return;
-    const bool plain_a = wv.out_aligned && plain_full_window(da, oa, g, num_values);
-    const bool plain_b = two && wv.out_aligned && plain_full_window(db, ob, (uint64_t)g + 1, num_values);
-    // the packed bytes of the plain ones, all loads first
-    uint4 va[3], vb[3];
-    uint32_t na = 0, nb = 0, ska = 0, skb = 0;
-    if (plain_a) {
-        const uint64_t p0 = desc_payload(da);
-        uint64_t p1 = p0 + plain_window_bytes(da);
-        if (p1 > len) p1 = len;  // (the plan has checked every run against the stream's length)
-        ska = (uint32_t)((uintptr_t)(s + p0) & 15);
-        na = p1 > p0 ? (uint32_t)((p1 - p0 + ska + 15) >> 4) : 0;
-        const uint4 *src = (const uint4 *)(s + p0 - ska);
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-            if (64u * i + wv.lane < na) va[i] = src[64u * i + wv.lane];
-    }
-    if (plain_b) {
-        const uint64_t p0 = desc_payload(db);
-        uint64_t p1 = p0 + plain_window_bytes(db);
-        if (p1 > len) p1 = len;
-        skb = (uint32_t)((uintptr_t)(s + p0) & 15);
-        nb = p1 > p0 ? (uint32_t)((p1 - p0 + skb + 15) >> 4) : 0;
-        const uint4 *src = (const uint4 *)(s + p0 - skb);
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-            if (64u * i + wv.lane < nb) vb[i] = src[64u * i + wv.lane];
-    }
-    auto put = [&](const uint4 (&v)[3], uint32_t n, uint32_t *lds) {
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-            if (64u * i + wv.lane < n) {
-                uint4 x = v[i];
-                x.x = __builtin_bswap32(x.x);
-                x.y = __builtin_bswap32(x.y);
-                x.z = __builtin_bswap32(x.z);
-                x.w = __builtin_bswap32(x.w);
-                ((uint4 *)lds)[64u * i + wv.lane] = x;
-            }
-    };
-    uint32_t *lds_b = wv.lds + HALF_STAGE_BYTES / 4;
-    if (plain_a) put(va, na, wv.lds);
-    if (plain_b) put(vb, nb, lds_b);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (plain_a) expand_plain_window(wv, out + ((uint64_t)g << WINDOW_SHIFT), da, ba, xa, ska * 8);
-    if (plain_b) {
-        WaveOf<MODE_VALUES> wb = wv;
-        wb.lds = lds_b;
-        expand_plain_window(wb, out + (((uint64_t)g + 1) << WINDOW_SHIFT), db, bb, xb, skb * 8);
-    }
-    // whatever is not plain, the general way (it stages for itself, after the plain ones are done
-    // with the slice)
-    if (!plain_a && (da & DESC_SINGLE)) decode_single_run(wv, da, oa, ba, xa);
-    if (two && !plain_b && (db & DESC_SINGLE)) decode_single_run(wv, db, ob, bb, xb);
+    if (desc & DESC_SINGLE) decode_single_run(wv, desc, out_off, base, aux);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2151,6 +2080,14 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_planned_values_kernel
 // and length (at least the values still wanted).
 // ---------------------------------------------------------------------------------------------
 
+// Raises a speculation flag.  A column that is not for a speculative path fails in most of its
+// wavefronts, and an atomic from each of them on the one word would queue up for longer than the
+// whole launch takes: the word is looked at first -- past the caches, which is affordable on this
+// path only -- and the atomic is left to the few that find it still clear.
+__device__ __forceinline__ void raise_flag(uint32_t *flag) {
+    if (*(const volatile uint32_t *)flag == 0) atomicOr(flag, 1u);
+}
+
 __device__ __forceinline__ uint32_t code_from_width(uint32_t w) {
     if (w >= 1 && w <= 24) return w - 1;
     if (w <= 32) return (w & 1) || w < 26 ? 0xFFu : 24 + (w - 26) / 2;
@@ -2160,8 +2097,8 @@ __device__ __forceinline__ uint32_t code_from_width(uint32_t w) {
 
 __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries, uint32_t n_seg,
-    uint32_t n_win, uint32_t runs_hint, uint64_t num_values, int is_signed, int64_t *__restrict__ out,
-    uint32_t *__restrict__ flag) {
+    uint32_t n_win, uint32_t runs_hint, uint32_t stride_vals, uint64_t seg_magic, uint64_t num_values,
+    int is_signed, int64_t *__restrict__ out, uint32_t *__restrict__ flag) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[VAL_WAVES][STAGE_WORDS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t wg = blockIdx.x;  // XCD-contiguous remap, as in rlev2_values_kernel
@@ -2171,8 +2108,11 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel
     }
     const uint32_t g = wg * VAL_WAVES + wave;
     if (g >= n_win) return;
-    // somebody found the column irregular: the rest of this launch is wasted work
-    if (__builtin_amdgcn_readfirstlane(*(const volatile uint32_t *)flag)) return;
+    // somebody found the column irregular: the rest of this launch is wasted work.  (A plain load,
+    // through the cache, and only looked at once the loads of the entry points are out as well: a
+    // load past the caches that is waited for here costs every wavefront a memory round trip of
+    // its own before it can ask for anything else.)
+    const uint32_t flag_now = *flag;
     WaveOf<MODE_VALUES> wv;
     wv.s = s;
     wv.lds = stage[wave];
@@ -2187,7 +2127,7 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel
     wv.acc = 0;
     wv.saw_patched = 0;
     auto fail = [&]() {
-        if (wv.lane == 0) atomicOr(flag, 1u);
+        if (wv.lane == 0) raise_flag(flag);
     };
     // How many runs lie between two entry points: the distance from the stream's start to its
     // second entry point over the size of the first run, which must be a Direct run of 512 values
@@ -2196,8 +2136,31 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel
     // (runs_hint: the counts of windows and entry points leave one possibility -- true of any column
     // of many segments -- and the host passes it; the checks below do not care where the number
     // comes from, and a wavefront that need not work it out starts on its bytes a round trip sooner)
-    uint32_t runs_per_seg = n_win;
-    if (n_seg > 1 && runs_hint != 0) {
+    // stride_vals: the segments hold that many values each, whatever that is in runs -- entry point
+    // q is the header of the run that holds value q * stride_vals, the first window of segment q is
+    // floor(q * stride_vals / 512), and a segment holds the windows up to the next one's first (the
+    // row groups of a file: 10 000 values make 19 or 20 runs).  seg_magic = 2^64 / stride_vals
+    // rounded up turns the division into a multiplication (exact below 2^23; checked all the same).
+    uint32_t runs_per_seg = n_win, seg = 0, first = 0;
+    if (n_seg > 1 && stride_vals != 0) {
+        const uint64_t S = stride_vals;
+        seg = (uint32_t)__umul64hi((((uint64_t)g + 1) << WINDOW_SHIFT) - 1, seg_magic);
+        if (seg >= n_seg) seg = n_seg - 1;
+        uint64_t fw = ((uint64_t)seg * S) >> WINDOW_SHIFT;
+        if (fw > g && seg > 0) {
+            seg--;
+            fw = ((uint64_t)seg * S) >> WINDOW_SHIFT;
+        }
+        uint64_t fw_next = seg + 1 < n_seg ? (((uint64_t)seg + 1) * S) >> WINDOW_SHIFT : (uint64_t)n_win;
+        if (fw_next <= g && seg + 1 < n_seg) {
+            seg++;
+            fw = fw_next;
+            fw_next = seg + 1 < n_seg ? (((uint64_t)seg + 1) * S) >> WINDOW_SHIFT : (uint64_t)n_win;
+        }
+        if (fw > g || fw_next <= g || fw_next > n_win) return fail();
+        first = (uint32_t)fw;
+        runs_per_seg = (uint32_t)(fw_next - fw);
+    } else if (n_seg > 1 && runs_hint != 0) {
         runs_per_seg = runs_hint;
         if ((uint64_t)runs_per_seg * (n_seg - 1) >= n_win) return fail();
     } else if (n_seg > 1) {
@@ -2212,9 +2175,12 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel
             (uint64_t)runs_per_seg * (n_seg - 1) >= n_win)
             return fail();
     }
-    uint32_t seg = g / runs_per_seg;
-    if (seg >= n_seg) seg = n_seg - 1;  // the last segment holds whatever is left
-    const uint32_t k = g - seg * runs_per_seg;
+    if (stride_vals == 0 || n_seg <= 1) {
+        seg = g / runs_per_seg;
+        if (seg >= n_seg) seg = n_seg - 1;  // the last segment holds whatever is left
+        first = seg * runs_per_seg;
+    }
+    const uint32_t k = g - first;
     const uint64_t e0 = (seg && entries) ? readfirstlane64(entries[seg]) : 0;
     if (e0 >= len) return fail();
     uint64_t size;
@@ -2232,6 +2198,7 @@ __global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_strided_values_kernel
         size = readfirstlane64(r.run_end - e0);
     }
     const uint64_t pos = e0 + (uint64_t)k * size;
+    if (__builtin_amdgcn_readfirstlane(flag_now)) return;
     if (pos >= len) return fail();
     const uint64_t wbase = (uint64_t)g << WINDOW_SHIFT;
     if (g + 1 == n_win) {  // the stream's last window
@@ -2264,9 +2231,10 @@ __global__ void spec_publish_kernel(uint32_t *__restrict__ flag, ScanTotals *hos
     if (threadIdx.x || blockIdx.x) return;
     volatile ScanTotals *h = host_totals;
     h->error = flag[0];
-    h->error_seg = flag[1];  // (what rlev2_regular_plan_kernel noted beside its verdict)
+    h->error_seg = flag[1];  // (what the planning kernels noted beside their verdict)
     flag[0] = 0;
     flag[1] = 0;
+    flag[2] = 0;  // (rlev2_selfplan_values_kernel's count of walks)
     __threadfence_system();
     h->pad = stamp;
 }
@@ -2274,13 +2242,15 @@ __global__ void spec_publish_kernel(uint32_t *__restrict__ flag, ScanTotals *hos
 hipError_t launch_rlev2_strided_values(hipStream_t st, const uint8_t *stream, uint64_t len,
                                        const uint64_t *entries, uint32_t n_seg, uint32_t n_win,
                                        uint64_t num_values, int is_signed, int64_t *out, uint32_t *flag,
-                                       ScanTotals *host_totals, uint32_t stamp) {
+                                       ScanTotals *host_totals, uint32_t stamp, uint32_t stride_vals) {
     if (n_win == 0 || n_seg == 0 || (((uintptr_t)out) & 15)) return hipErrorInvalidValue;
     const uint32_t blocks = (n_win + VAL_WAVES - 1) / VAL_WAVES;
     uint32_t r_lo = 0, r_hi = 0, runs_hint = 0;
     if (rlev2_regular_plan_shape(n_seg, n_win, &r_lo, &r_hi) && r_lo == r_hi) runs_hint = r_lo;
+    if (stride_vals && (stride_vals < WINDOW || stride_vals >= (1u << 23) || n_seg < 2)) stride_vals = 0;
+    const uint64_t magic = stride_vals ? ~0ull / stride_vals + 1 : 0;
     rlev2_strided_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, entries, n_seg, n_win, runs_hint,
-                                                                  num_values, is_signed, out, flag);
+                                                                  stride_vals, magic, num_values, is_signed, out, flag);
     spec_publish_kernel<<<1, 64, 0, st>>>(flag, host_totals, stamp);
     return hipGetLastError();
 }
@@ -2459,7 +2429,7 @@ __device__ __forceinline__ RunEntry plan_window(
     const uint64_t next_pos = shfl64(pos, (int)(lane < 63 ? lane + 1 : 63));
     const bool linked = live && lane < 63 && g + 1 < n_win && !bad;
     if (linked && r.run_end != next_pos) bad = true;
-    if (live && bad) atomicOr(flag, 1u);
+    if (live && bad) raise_flag(flag);
     // flag[1]: some run is not a Direct run, or not of its successor's size -- a column that
     // leaves it zero is one the strided kernel decodes without this pass
     const uint64_t size = r.run_end - pos;
@@ -2483,7 +2453,7 @@ __global__ __launch_bounds__(256) void rlev2_regular_plan_kernel(
     const uint64_t wave_id = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const uint64_t g64 = wave_id * 63 + lane;
     if (wave_id * 63 >= n_win) return;  // whole wavefront
-    if (__builtin_amdgcn_readfirstlane(*(const volatile uint32_t *)flag)) return;
+    if (__builtin_amdgcn_readfirstlane(*flag)) return;  // (through the cache: it only saves time)
     const RunEntry e = plan_window(s, len, entries, n_seg, n_win, r_lo, r_hi, num_values, is_signed, g64, lane,
                                    g64 < n_win, flag);
     if (e.desc != 0) group_run[g64] = e;
@@ -2496,6 +2466,334 @@ bool rlev2_regular_plan_shape(uint32_t n_seg, uint32_t n_win, uint32_t *r_lo, ui
     *r_hi = (n_win - 1) / (n_seg - 1);
     return *r_lo <= *r_hi;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Plan and expansion in one launch, for the same kind of column -- every 512 values one run of 512
+// values, the runs of a segment alike in kind and width -- and for segments of unequal run counts:
+// row group k of a file starts at value k * S (S = the row index stride, 10 000 by default, no
+// multiple of 512), so its entry point is the header of run floor(k * S / 512) and a segment holds
+// 19 or 20 runs.  Window g then lies in the last segment whose first window is not after it, and
+// that is arithmetic.
+//
+// A wavefront does for its window what a lane of rlev2_regular_plan_kernel does, on bytes it must
+// stage anyway: it stages the stream from 16 bytes before the interpolated position of its run to
+// 18 bytes after the interpolated position of the next, looks in the first 32 positions for the
+// two bytes that every 512-value header of the segment's kind and width starts with (lanes 0..31)
+// and, in the 32 positions around the next run's, for the same (lanes 32..63).  One hit is the
+// choice; the segment's first run is at the entry point and the run after its last at the next
+// entry point, no search.  The header is parsed out of LDS, the run must hold 512 values and end
+// exactly at the next window's choice -- which the next wavefront arrives at by the same arithmetic
+// on the same bytes -- and so, by induction from the entry point, every position used is one a walk
+// of the header chain reaches (rle_v2.rs:441-461, 480-514).  No hit or several (two bytes of
+// payload can look like a header: about one window in two thousand): the wavefront walks the chain
+// from the entry point, which proves its position by itself; it still checks its end against the
+// next choice, because the next wavefront trusts that choice.  A next choice that is ambiguous
+// needs no check: that wavefront walks.  Windows that are not plain -- the column's last, fields
+// wider than 32 bits, PatchedBase, Delta without packed deltas -- go through the general
+// single-run code.  Anything that does not hold raises *flag, and so do too many walks (a column
+// whose runs are a few bytes long has several headers in every 32 positions: it is not for this
+// path); the caller then decodes the stream another way.
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t lds_byte(const uint32_t *lds, uint32_t idx) {
+    return (lds[idx >> 2] >> (24u - 8u * (idx & 3u))) & 0xFFu;  // (the words are byte-swapped)
+}
+
+// The two bytes at idx, idx + 1 of the slice, first byte in the high half.
+__device__ __forceinline__ uint32_t lds_be16(const uint32_t *lds, uint32_t idx) {
+    const uint32_t d = idx >> 2;
+    const uint64_t x = ((uint64_t)lds[d] << 32) | lds[d + 1];
+    return (uint32_t)((x << (8u * (idx & 3u))) >> 48);
+}
+
+// The seven bits of each of the eight bytes of x, lowest byte first, packed into 56 bits (the value
+// of a varint of eight bytes whose continuation bits are ignored).
+__device__ __forceinline__ uint64_t compress7(uint64_t x) {
+    x = ((x & 0x7F007F007F007F00ull) >> 1) | (x & 0x007F007F007F007Full);
+    x = ((x & 0x3FFF00003FFF0000ull) >> 2) | (x & 0x00003FFF00003FFFull);
+    x = ((x & 0x0FFFFFFF00000000ull) >> 4) | (x & 0x000000000FFFFFFFull);
+    return x;
+}
+
+constexpr uint32_t SELFPLAN_REACH = 16;   // positions searched on either side of the guess
+constexpr uint32_t SELFPLAN_MAX_RUN = 4200;  // bytes: no run of 512 values is longer (4 + 8 + 4096 + 62)
+constexpr uint32_t STEP_FRAC_BITS = 20;
+
+// What the wavefronts of a segment share, worked out once per segment by a lane of
+// rlev2_selfplan_segments_kernel so that a wavefront gets it in one load: where the segment's
+// first run is, how far apart its runs are expected (the distance to the next entry point over the
+// runs in between, in 2^-20ths of a byte; the last segment borrows the one before's), which
+// windows it holds and what its first header byte is.
+struct SegPlan {
+    uint64_t e0;
+    uint64_t step;
+    uint32_t first_win;
+    uint32_t n_win;
+    uint32_t h0;
+    uint32_t pad;
+};
+
+// first window of segment q when entry q is the header of the run that holds value q * S
+__host__ __device__ inline uint64_t seg_first_win(uint64_t q, uint64_t S) { return (q * S) >> WINDOW_SHIFT; }
+
+// Segment table [n_seg + 1] (the last entry a sentinel at the end of the stream); anything that does
+// not fit -- entry points out of order or out of the stream, a segment without a window, runs
+// that would have to be longer than a run can be -- raises *flag.
+__global__ __launch_bounds__(256) void rlev2_selfplan_segments_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries, uint32_t n_seg,
+    uint32_t n_win, uint64_t S, SegPlan *__restrict__ table, uint32_t *__restrict__ flag) {
+    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg > n_seg) return;
+    SegPlan p = {len, 0, n_win, 0, 0, 0};
+    if (seg < n_seg) {
+        const bool last = seg + 1 == n_seg;
+        const uint64_t fw = seg_first_win(seg, S), fw_next = last ? (uint64_t)n_win : seg_first_win((uint64_t)seg + 1, S);
+        const uint64_t e0 = seg ? entries[seg] : 0;
+        uint64_t ea = e0, eb = last ? e0 : entries[seg + 1], runs = fw_next - fw;
+        if (last) {  // no entry point follows: the spacing of the segment before
+            ea = seg > 1 ? entries[seg - 1] : 0;
+            runs = fw - seg_first_win(seg ? seg - 1 : 0, S);
+        }
+        const bool ok = fw < fw_next && fw_next <= n_win && e0 < len && eb > ea && eb <= len && runs > 0 &&
+                        eb - ea <= runs * SELFPLAN_MAX_RUN && fw <= 0xFFFFFFFFull;
+        if (!ok) {
+            raise_flag(flag);
+        } else {
+            p.e0 = e0;
+            p.step = ((eb - ea) << STEP_FRAC_BITS) / runs;
+            p.first_win = (uint32_t)fw;
+            p.n_win = (uint32_t)(fw_next - fw);
+            p.h0 = s[e0];
+        }
+    }
+    table[seg] = p;
+}
+
+__global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_selfplan_values_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const SegPlan *__restrict__ table, uint32_t n_seg,
+    uint32_t n_win, uint64_t seg_magic, uint64_t num_values, int is_signed,
+    int64_t *__restrict__ out, uint32_t *__restrict__ flag) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[VAL_WAVES][STAGE_WORDS];
+    __shared__ uint32_t patch_tab[VAL_WAVES][PATCH_TAB_WORDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t wg = blockIdx.x;  // XCD-contiguous remap, as in rlev2_values_kernel
+    {
+        const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = wg % 8;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
+    }
+    const uint32_t g = wg * VAL_WAVES + wave;
+    if (g >= n_win) return;  // whole wavefront; no workgroup barrier below
+    // somebody found the column irregular: the rest of this launch is wasted work (read through the
+    // cache: it only saves time; looked at further down, when the loads behind it are on their way)
+    const uint32_t flag_now = *flag;
+    WaveOf<MODE_VALUES> wv;
+    wv.s = s;
+    wv.lds = stage[wave];
+    wv.marks = nullptr;
+    wv.patch_tab = patch_tab[wave];
+    wv.out = out;
+    wv.num_values = num_values;
+    wv.len = len;
+    wv.lane = threadIdx.x & 63;
+    wv.is_signed = is_signed;
+    wv.out_aligned = true;  // the launcher insists
+    wv.acc = 0;
+    wv.saw_patched = 0;
+    const uint32_t lane = (uint32_t)wv.lane;
+    auto fail = [&]() {
+        if (lane == 0) raise_flag(flag);
+    };
+    // ---- which segment, which run of it ------------------------------------------------------
+    // floor(((g + 1) * 512 - 1) / S) by a multiplication with seg_magic = 2^64 / S rounded up: the
+    // last segment that starts at or before the window (exact for any S below 2^23; the table's
+    // window ranges are checked all the same)
+    uint32_t seg = (uint32_t)__umul64hi((((uint64_t)g + 1) << WINDOW_SHIFT) - 1, seg_magic);
+    if (seg >= n_seg) seg = n_seg - 1;
+    SegPlan sp = table[seg], sp_next = table[seg + 1];
+    for (int hops = 0; hops < 2 && g < sp.first_win && seg > 0; hops++) {
+        seg--;
+        sp_next = sp;
+        sp = table[seg];
+    }
+    for (int hops = 0; hops < 2 && g - sp.first_win >= sp.n_win && seg + 1 < n_seg; hops++) {
+        seg++;
+        sp = sp_next;
+        sp_next = table[seg + 1];
+    }
+    if (g < sp.first_win || g - sp.first_win >= sp.n_win) return fail();
+    const bool last_seg = seg + 1 == n_seg;
+    const uint32_t k = g - sp.first_win, R = sp.n_win;
+    const uint64_t e0 = readfirstlane64(sp.e0), eb = readfirstlane64(sp_next.e0), step = readfirstlane64(sp.step);
+    const bool is_last_win = g + 1 == n_win;
+    const bool next_is_entry = !last_seg && k + 1 == R;  // the next run is the next segment's first
+    // own: positions A .. A + 31 are searched (k == 0: the entry point, no search); run j of the
+    // segment is expected at e0 + j * step, a function of the table alone and so the same for the
+    // wavefront of the window and for that of the window before
+    uint64_t A = e0;
+    if (k != 0) {
+        const uint64_t mid = e0 + (((uint64_t)k * step) >> STEP_FRAC_BITS);
+        A = mid > e0 + SELFPLAN_REACH ? mid - SELFPLAN_REACH : e0 + 1;
+    }
+    // next: positions B .. B + 31
+    uint64_t B = next_is_entry ? eb : 0;
+    if (!next_is_entry && !is_last_win) {
+        const uint64_t mid = e0 + ((((uint64_t)k + 1) * step) >> STEP_FRAC_BITS);
+        B = mid > e0 + SELFPLAN_REACH ? mid - SELFPLAN_REACH : e0 + 1;
+    }
+    A = readfirstlane64(A);
+    B = readfirstlane64(B);
+    const uint32_t h0 = __builtin_amdgcn_readfirstlane(sp.h0);
+    // ---- stage [A, hi) ------------------------------------------------------------------------
+    uint64_t hi = is_last_win ? A + 64 : (next_is_entry ? B + 2 : B + 2 * SELFPLAN_REACH + 2);
+    if (hi > len) hi = len;
+    if (A >= len || hi <= A || hi - A > STAGE_BYTES - 16) return fail();
+    const uint64_t origin = stage_bytes(wv, A, hi);
+    if (__builtin_amdgcn_readfirstlane(flag_now)) return;
+    const uint32_t oA = (uint32_t)(A - origin), staged_end = (uint32_t)(hi - origin);  // LDS byte indices
+    // ---- the two searches, 32 lanes each --------------------------------------------------------
+    uint64_t own = k == 0 ? e0 : ~0ull, next = next_is_entry ? eb : ~0ull;  // ~0: no choice
+    bool next_wanted = !is_last_win;
+    {
+        const uint32_t at = ((lane >> 5) ? (uint32_t)(B - origin) : oA) + (lane & 31u);
+        const bool inside = at + 1 < staged_end && (lane >> 5 ? (next_wanted && !next_is_entry) : k != 0);
+        const uint32_t two = inside ? lds_be16(wv.lds, at) : 0u;
+        const uint64_t hits = __ballot(inside && two == ((h0 << 8) | 0xFFu));
+        const uint32_t mine = (uint32_t)hits, theirs = (uint32_t)(hits >> 32);
+        if (k != 0 && __builtin_popcount(mine) == 1) own = A + (uint32_t)__builtin_ctz(mine);
+        if (next_wanted && !next_is_entry && __builtin_popcount(theirs) == 1) next = B + (uint32_t)__builtin_ctz(theirs);
+    }
+    const uint64_t wbase = (uint64_t)g << WINDOW_SHIFT;
+    // ---- the plain window: header out of LDS ----------------------------------------------------
+    bool plain = own != ~0ull && !is_last_win && wbase + WINDOW <= num_values;
+    uint32_t kind = 0, w = 0, header_bytes = 2;
+    uint64_t base = 0, dbase = 0;
+    if (plain) {
+        // the 24 bytes from the header on as scalars, lowest address in the lowest byte: seven
+        // lanes fetch a word each, and everything after that is scalar arithmetic
+        const uint32_t o = (uint32_t)(own - origin);
+        const uint32_t wi = (o >> 2) + (lane < 7 ? lane : 0u);
+        const uint32_t dw = __builtin_bswap32(wv.lds[wi < STAGE_WORDS ? wi : 0u]);
+        const uint64_t q0 = ((uint64_t)readlane32(dw, 1) << 32) | readlane32(dw, 0);
+        const uint64_t q1 = ((uint64_t)readlane32(dw, 3) << 32) | readlane32(dw, 2);
+        const uint64_t q2 = ((uint64_t)readlane32(dw, 5) << 32) | readlane32(dw, 4);
+        const uint64_t q3 = readlane32(dw, 6);
+        // (a shift by 64 - sh in two steps, so that sh = 0 needs no case of its own)
+        const uint32_t sh = 8u * (o & 3u);
+        const uint64_t x0 = (q0 >> sh) | ((q1 << 1) << (63 - sh));
+        const uint64_t x1 = (q1 >> sh) | ((q2 << 1) << (63 - sh));
+        const uint64_t x2 = (q2 >> sh) | ((q3 << 1) << (63 - sh));
+        const uint32_t b0 = (uint32_t)x0 & 0xFFu, b1 = (uint32_t)(x0 >> 8) & 0xFFu;
+        kind = b0 >> 6;
+        const uint32_t code = (b0 >> 1) & 31u;
+        plain = (b0 & 1u) && b1 == 0xFFu && (kind == KIND_DIRECT || (kind == KIND_DELTA && code != 0));  // 512 values
+        w = width_from_code(code);
+        plain = plain && w <= 32 && o + 24 <= staged_end;
+        if (plain && kind == KIND_DELTA) {
+            // the two varints (rle_v2.rs:71-89), of at most eight bytes each here: a longer one
+            // sends the window to the general code
+            const uint64_t tops = 0x8080808080808080ull;
+            const uint64_t va = (x0 >> 16) | (x1 << 48);  // header bytes 2 .. 9
+            const uint64_t vb = (x1 >> 16) | (x2 << 48);  // 10 .. 17
+            const uint64_t e1 = ~va & tops;
+            const uint32_t n1 = e1 ? ((uint32_t)__builtin_ctzll(e1) >> 3) + 1u : 9u;
+            const uint32_t m1 = n1 <= 8 ? n1 : 8u;  // (shift counts stay in range when there is no end)
+            const uint64_t ya = ((va >> (8 * m1 - 1)) >> 1) | (vb << (64 - 8 * m1));
+            const uint64_t e2 = ~ya & tops;
+            const uint32_t n2 = e2 ? ((uint32_t)__builtin_ctzll(e2) >> 3) + 1u : 9u;
+            plain = n1 <= 8 && n2 <= 8;
+            if (plain) {
+                const uint64_t v1 = compress7(va & (~0ull >> (64 - 8 * n1)));
+                const uint64_t v2 = compress7(ya & (~0ull >> (64 - 8 * n2)));
+                base = is_signed ? zigzag(v1) : v1;  // rle_v2.rs:350
+                dbase = zigzag(v2);                    // rle_v2.rs:100-102, 351
+                header_bytes = 2 + n1 + n2;
+            }
+        }
+    }
+    if (plain) {
+        const uint64_t payload = own + header_bytes;
+        const uint32_t fields = kind == KIND_DELTA ? WINDOW - 2 : WINDOW;
+        const uint64_t run_end = payload + ((fields * w + 7) >> 3);
+        if (run_end - origin > staged_end) plain = false;  // (not all staged: the general code looks again)
+        else {
+            if (next_wanted && next != ~0ull && run_end != next) return fail();  // the link
+            const uint32_t bit0 = (uint32_t)(payload - origin) << 3;
+            int64_t *wout = out + wbase;
+            if (kind == KIND_DIRECT) {
+                direct_window<true, false>(wv, wout, w, is_signed != 0, 0, bit0 + 2u * lane * w, 0, WINDOW);
+            } else {
+                const bool neg = (int64_t)dbase < 0;
+                if (w <= 16) {
+                    if (neg) delta_window_full<true, false, uint32_t, true>(wv, wout, w, base, dbase, bit0);
+                    else delta_window_full<true, false, uint32_t, false>(wv, wout, w, base, dbase, bit0);
+                } else if (w <= 23) {
+                    if (neg) delta_window_full<false, false, uint32_t, true>(wv, wout, w, base, dbase, bit0);
+                    else delta_window_full<false, false, uint32_t, false>(wv, wout, w, base, dbase, bit0);
+                } else {
+                    if (neg) delta_window_full<false, false, uint64_t, true>(wv, wout, w, base, dbase, bit0);
+                    else delta_window_full<false, false, uint64_t, false>(wv, wout, w, base, dbase, bit0);
+                }
+            }
+            return;
+        }
+    }
+    // ---- everything else: position by the search or by a walk of the chain, then the general code --
+    uint64_t pos = own;
+    if (pos == ~0ull) {
+        // (counted: a column where this is the rule is not for this path)
+        if (lane == 0 && atomicAdd(flag + 2, 1u) > (n_win >> 5) + 64u) raise_flag(flag);
+        pos = e0;
+        for (uint32_t j = 0; j < k; j++) {
+            ParsedRun hop;
+            if (pos >= len || parse_run(load_window(s, len, pos), s, len, pos, is_signed, hop) != SEG_OK ||
+                hop.len != WINDOW)
+                return fail();
+            pos = readfirstlane64(hop.run_end);
+        }
+    }
+    ParsedRun r;
+    if (pos >= len || parse_run(load_window(s, len, pos), s, len, pos, is_signed, r) != SEG_OK) return fail();
+    if (is_last_win) {
+        // the column's last run: any length that holds the values still wanted
+        if (wbase >= num_values || (uint64_t)r.len < num_values - wbase) return fail();
+    } else {
+        if (r.len != WINDOW) return fail();
+        if (next != ~0ull && readfirstlane64(r.run_end) != next) return fail();  // the link
+    }
+    const uint64_t desc = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes);
+    decode_single_run(wv, readfirstlane64(desc), wbase, readfirstlane64(r.base), readfirstlane64(r.aux));
+}
+
+hipError_t launch_rlev2_selfplan_values(hipStream_t st, const uint8_t *stream, uint64_t len,
+                                        const uint64_t *entries, uint32_t n_seg, uint32_t n_win,
+                                        uint32_t stride_vals, uint64_t num_values, int is_signed, int64_t *out,
+                                        uint32_t *flag, void *seg_table) {
+    if (!entries || !seg_table || (((uintptr_t)out) & 15) || !rlev2_selfplan_shape(n_seg, n_win, stride_vals))
+        return hipErrorInvalidValue;
+    uint64_t S = stride_vals;
+    if (S == 0) {  // equally many runs in every segment: the counts leave one possibility
+        uint32_t r_lo = 0, r_hi = 0;
+        (void)rlev2_regular_plan_shape(n_seg, n_win, &r_lo, &r_hi);
+        S = (uint64_t)r_lo << WINDOW_SHIFT;
+    }
+    const uint64_t magic = ~0ull / S + 1;  // 2^64 / S rounded up (S >= 512 is no divisor that gives 2^64)
+    rlev2_selfplan_segments_kernel<<<(n_seg + 1 + 255) / 256, 256, 0, st>>>(stream, len, entries, n_seg, n_win, S,
+                                                                            (SegPlan *)seg_table, flag);
+    const uint32_t blocks = (n_win + VAL_WAVES - 1) / VAL_WAVES;
+    rlev2_selfplan_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, (const SegPlan *)seg_table, n_seg, n_win,
+                                                                   magic, num_values, is_signed, out, flag);
+    return hipGetLastError();
+}
+
+size_t rlev2_selfplan_table_bytes(uint32_t n_seg) { return ((size_t)n_seg + 1) * sizeof(SegPlan); }
+
+bool rlev2_selfplan_shape(uint32_t n_seg, uint32_t n_win, uint32_t stride_vals) {
+    if (n_seg < 2 || n_win == 0) return false;
+    if (stride_vals) return stride_vals >= WINDOW && stride_vals < (1u << 23);
+    uint32_t r_lo = 0, r_hi = 0;
+    return rlev2_regular_plan_shape(n_seg, n_win, &r_lo, &r_hi) && r_lo == r_hi && r_lo < (1u << 14);
+}
+
 
 hipError_t launch_rlev2_regular_plan(hipStream_t st, const uint8_t *stream, uint64_t len,
                                      const uint64_t *entries, uint32_t n_seg, uint32_t n_win,
@@ -2660,20 +2958,9 @@ hipError_t launch_rlev2_resync(hipStream_t st, const uint8_t *stream, uint64_t l
 hipError_t launch_rlev2_planned_values(hipStream_t st, const Rlev2Table &t, int64_t *out,
                                        const uint32_t *abort_flag) {
     if (t.n_groups == 0) return hipSuccess;
-    static const int variant = [] {
-        const char *e = getenv("ORCD_EXP_PLANNED");
-        return e ? atoi(e) : 1;
-    }();
-    if (variant == 0) return launch_values_mode<MODE_VALUES>(st, t, out, nullptr, const_cast<uint32_t *>(abort_flag));
-    if (variant == 1) {
-        const uint32_t blocks = (t.n_groups + VAL_WAVES - 1) / VAL_WAVES;
-        rlev2_planned_values_kernel<false><<<blocks, VAL_WAVES * 64, 0, st>>>(t.stream, t.len, t.group_run, t.n_groups,
-                                                                             t.num_values, t.is_signed, out, abort_flag);
-    } else {
-        const uint32_t blocks = ((t.n_groups + 1) / 2 + VAL_WAVES - 1) / VAL_WAVES;
-        rlev2_planned_values_kernel<true><<<blocks, VAL_WAVES * 64, 0, st>>>(t.stream, t.len, t.group_run, t.n_groups,
-                                                                            t.num_values, t.is_signed, out, abort_flag);
-    }
+    const uint32_t blocks = (t.n_groups + VAL_WAVES - 1) / VAL_WAVES;
+    rlev2_planned_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(t.stream, t.len, t.group_run, t.n_groups,
+                                                                  t.num_values, t.is_signed, out, abort_flag);
     return hipGetLastError();
 }
 

@@ -150,6 +150,11 @@ class Column:
         buf = (C.c_uint64 * n.value).from_address(ptr.value)
         return np.frombuffer(buf, dtype=np.uint64).copy()
 
+    def values_per_group(self, kind):
+        """orcd_column_values_per_group: values of stream `kind` between two entry points when the
+        index's values-to-skip are those of runs of 512 values throughout, else 0."""
+        return int(self._lib.orcd_column_values_per_group(self._metadata._h, self._h, int(kind)))
+
 
 class _Owned(np.ndarray):
     """numpy view that keeps the owning Column alive."""

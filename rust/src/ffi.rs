@@ -155,6 +155,9 @@ extern "C" {
     pub fn orcd_rlev2_decode(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_values: usize,
                              entry_points: *const u64, n_entries: usize, out: *mut i64,
                              flags: c_uint) -> c_int;
+    pub fn orcd_rlev2_decode_groups(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_values: usize,
+                                    entry_points: *const u64, n_entries: usize, values_per_group: u64,
+                                    out: *mut i64, flags: c_uint) -> c_int;
     pub fn orcd_inflate_chunks(ctx: *mut orcd_ctx, src: *const u8, src_len: usize,
                                chunks: *const orcd_chunk, n_chunks: usize, dst: *mut u8,
                                dst_len: usize, sizes: *mut u32, flags: c_uint) -> c_int;
@@ -235,6 +238,7 @@ extern "C" {
     pub fn orcd_file_read_at(file: *mut orcd_file, offset: u64, len: u64, dst: *mut u8) -> c_int;
     pub fn orcd_column_entry_points(file: *mut orcd_file, column: *mut orcd_column, kind: c_int,
                                     entries: *mut *const u64, n_entries: *mut usize) -> c_int;
+    pub fn orcd_column_values_per_group(file: *mut orcd_file, column: *mut orcd_column, kind: c_int) -> u64;
 
     // whole columns (the deserialize_* functions of tests/it/deserialize.rs:13-222)
     pub fn orcd_decode_column(ctx: *mut orcd_ctx, file: *mut orcd_file, stripe: usize,
