@@ -50,7 +50,9 @@ DEFAULT_ROWS = {"strings_w6": 250_000_000, "boolean_mix": 4_000_000_000, "mixed_
                 "mixed_short_runs_sparse": 500_000_000}
 
 
-EXTRA_WORKLOADS = ["delta_w10", "delta_w16", "mixed_short_runs", "boolean_mix", "strings_w6", "strings_file"]
+EXTRA_WORKLOADS = ["delta_w10", "delta_w16", "mixed_short_runs", "boolean_mix", "strings_w6", "strings_file",
+                   "real_file_direct", "real_file_delta", "mixed_table"]
+FILE_WORKLOADS = ["strings_file", "zlib_file", "real_file_direct", "real_file_delta", "mixed_table"]
 # strings_file: the string configuration as an ORC file, end to end (read + H2D + decode + D2H of
 # the offsets); stripes of 2 000 000 strings, about 64 MB of DATA each
 FILE_STRIPES, FILE_STRINGS_PER_STRIPE = 32, 2_000_000
@@ -83,7 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=None,
                     help="values per GPU per step (default 1e9; 2.5e8 strings for strings_w6)")
-    ap.add_argument("--workload", default="direct_w17", choices=sorted(WORKLOADS) + ["strings_file", "zlib_file"])
+    ap.add_argument("--workload", default="direct_w17", choices=sorted(WORKLOADS) + FILE_WORKLOADS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the `workloads` object (the other configurations, shorter runs)")
@@ -134,11 +136,15 @@ def main():
             sub.rows, sub.steps, sub.warmup = None, min(args.steps, 10), min(args.warmup, 2)
             sub.cpu_seconds, sub.end_to_end = min(args.cpu_seconds, 4.0), False
             torch.cuda.empty_cache()
-            r = run_workload(sub, wl, rank, world, local_rank, dist, torch, np)
+            try:
+                r = run_workload(sub, wl, rank, world, local_rank, dist, torch, np)
+            except ImportError as e:   # (the file workloads need pyarrow's writer on the host)
+                result["workloads"][wl] = {"skipped": "%s: %s" % (type(e).__name__, e)}
+                continue
             keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "roofline",
                                       "phases_ms", "decoded_frac_of_hbm_peak", "cpu_baseline",
-                                      "zero_copy_variant", "decoded_GBps") if k in r}
-            if wl != "strings_file":
+                                      "zero_copy_variant", "decoded_GBps", "path", "per_stripe_ms", "skipped") if k in r}
+            if wl not in ("strings_file", "mixed_table"):
                 keep.pop("metric", None)  # (the headline's metric)
             keep["workload"] = r["config"]["workload"]
             result["workloads"][wl] = keep
@@ -172,6 +178,14 @@ def run_workload(args, workload, rank, world, local_rank, dist, torch, np):
         args = argparse.Namespace(**vars(args))
         args.workload = workload
         return bench_strings_file(args, rank, world, local_rank, dist, torch, np)
+    if workload in ("real_file_direct", "real_file_delta"):
+        args = argparse.Namespace(**vars(args))
+        args.workload = workload
+        return bench_real_file(args, rank, world, local_rank, dist, torch, np)
+    if workload == "mixed_table":
+        args = argparse.Namespace(**vars(args))
+        args.workload = workload
+        return bench_mixed_table(args, rank, world, local_rank, dist, torch, np)
     gen_name, gen_kw, signed, desc = WORKLOADS[workload]
     args = argparse.Namespace(**vars(args))
     args.workload = workload
@@ -526,6 +540,263 @@ def bench_strings_file(args, rank, world, local_rank, dist, torch, np):
                    "file_bytes_per_gpu": size, "stripes": n_stripes,
                    "parallelism": "stripe-sharded x%d" % world},
     }
+
+
+def bench_real_file(args, rank, world, local_rank, dist, torch, np):
+    """One step = the DATA streams of an int64 column of a file written by the Apache ORC C++ writer
+    (pyarrow), every stripe of it, decoded where they lie in HBM with the entry points the file's own
+    ROW_INDEX gives (orcd_rlev2_decode_groups: a position per row group of 10 000 values, which is
+    19 or 20 runs of 512).  real_file_direct: values below 2^16, written with
+    compression_strategy='compression' -> 17-bit Direct runs; real_file_delta: sorted timestamps ->
+    Delta runs.  What is timed is the decode proper, as for the synthetic columns; `path` says which
+    way the calls went (1 strided, 2 planned, 0 general)."""
+    import shutil
+    import tempfile
+    import pyarrow as pa
+    import pyarrow.orc as orc
+    from orc_format_amd import Context, read, shard
+
+    rows = args.rows or 100_000_000
+    rng = np.random.default_rng((7 if args.workload == "real_file_direct" else 8) + 1000 * rank)
+    if args.workload == "real_file_direct":
+        values = rng.integers(0, 2**16, size=rows)
+        what = "values U[0, 2^16), compression_strategy='compression': Direct runs of 17 bits"
+    else:
+        values = 1_600_000_000_000 + np.cumsum(rng.integers(1, 1000, size=rows))
+        what = "sorted timestamps, steps U[1, 1000): Delta runs"
+    tmp = tempfile.mkdtemp(prefix="orcd_bench_")
+    try:
+        path = os.path.join(tmp, "%s_%d.orc" % (args.workload, rank))
+        orc.write_table(pa.table({"v": pa.array(values)}), path, compression="uncompressed",
+                        compression_strategy="compression", stripe_size=1 << 30)
+        md = read.read_metadata(path)
+        stripes = []
+        first = 0
+        stream_bytes = 0
+        for k, st in enumerate(md.stripes):
+            footer = read.read_stripe_footer(md, k)
+            col = read.read_stripe_column(md, k, footer, 1)
+            data = col.get_stream(1)
+            ent = col.entry_points(1)
+            d_stream = torch.from_numpy(np.array(data)).cuda()
+            d_ent = torch.from_numpy(ent.astype(np.int64)).cuda()
+            stripes.append((d_stream, d_ent, int(st.number_of_rows), first, col.values_per_group(1)))
+            first += int(st.number_of_rows)
+            stream_bytes += int(d_stream.numel())
+        assert first == rows
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    expect = torch.from_numpy(values).cuda()
+    out = torch.empty(rows, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx = Context(local_rank)
+    paths = set()
+
+    def step():
+        for d_stream, d_ent, n, at, vpg in stripes:
+            ctx.rlev2_device(d_stream.data_ptr(), d_stream.numel(), n, True, out.data_ptr() + 8 * at,
+                             d_ent.data_ptr(), d_ent.numel(), values_per_group=vpg)
+            paths.add(ctx.last_path())
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    out.zero_()
+    paths.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist, device=REDUCE_DEVICE)
+    if not torch.equal(out, expect):
+        raise SystemExit("bench.py: %s: decoded column differs from what was written" % args.workload)
+    value = rows * 8 * args.steps * world / elapsed / 1e9
+    return {
+        "metric": "device-resident decoded GB/s (RLEv2 int64 + strings) at 1/2/4/8 GPUs",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "decoded_frac_of_hbm_peak": round(value / world / HBM_PEAK_GBPS, 4),
+        "path": sorted(paths),
+        "config": {"workload": "%s: %d rows per GPU per step in %d stripe(s) of a pyarrow-written ORC file; %s; "
+                               "entry points and values per row group (%s) from the file's ROW_INDEX"
+                               % (args.workload, rows, len(stripes), what, sorted({s[4] for s in stripes})),
+                   "rows_per_gpu": rows, "stream_bytes_per_gpu": stream_bytes, "stripes": len(stripes),
+                   "parallelism": "stripe-sharded x%d" % world},
+    }
+
+
+def bench_mixed_table(args, rank, world, local_rank, dist, torch, np):
+    """One step = one pass over this rank's mixed-schema ORC file (the Apache ORC C++ writer through
+    pyarrow): low-cardinality int keys in runs of geometric length (ShortRepeat / short Direct runs),
+    a nullable int64 column with 10 % nulls (PRESENT + DATA), a float64 and a boolean column.  From
+    the file's bytes (page cache) to row-aligned columns on the GPU: stripe reads, host-to-device
+    copies, PRESENT -> validity, DATA -> values, null scatter (orcd_decode_stripe with
+    ORCD_OUT_DEVICE | ORCD_ROW_ALIGNED), FILE_CONTEXTS contexts with a host thread each and the next
+    stripe read ahead.  Like strings_file it measures a whole path -- the feed bounds it -- and
+    carries no roofline of its own; `per_stripe_ms` is one context alone, nothing read ahead: the
+    host's time until the stripe's bytes are on their way to the device, and from then to the
+    decoded columns."""
+    import shutil
+    import tempfile
+    import pyarrow as pa
+    import pyarrow.orc as orc
+    from orc_format_amd import Context, read, shard
+
+    rows = args.rows or 100_000_000
+    rng = np.random.default_rng(44 + 1000 * rank)
+    # keys: values 0..15, each repeated a geometric number of times (mean 4)
+    n_runs = rows // 3
+    reps = rng.geometric(0.25, size=n_runs)
+    keys = np.repeat(rng.integers(0, 16, size=n_runs).astype(np.int32), reps)[:rows]
+    if keys.size < rows:
+        keys = np.concatenate([keys, np.zeros(rows - keys.size, dtype=np.int32)])
+    nulls = rng.random(rows) < 0.1
+    table = pa.table({
+        "key": pa.array(keys),
+        "val": pa.array(rng.integers(-2**40, 2**40, size=rows), mask=nulls),
+        "x": pa.array(rng.standard_normal(rows)),
+        "flag": pa.array(rng.random(rows) < 0.5),
+    })
+    del keys, reps
+    tmp = tempfile.mkdtemp(prefix="orcd_bench_")
+    try:
+        path = os.path.join(tmp, "mixed_%d.orc" % rank)
+        orc.write_table(table, path, compression="uncompressed", stripe_size=64 << 20)
+        size = os.path.getsize(path)
+        md = read.read_metadata(path)
+        n_stripes = len(md.stripes)
+        contexts = [Context(local_rank) for _ in range(FILE_CONTEXTS)]
+        # parity of the first stripe with what was written, row by row
+        ft0 = read.read_stripe_footer(md, 0)
+        first = contexts[0].decode_stripe(md, 0, ft0, [1, 2, 3, 4], row_aligned=True)
+        n0 = int(md.stripes[0].number_of_rows)
+        for k, name in enumerate(["key", "val", "x", "flag"]):
+            want = table.column(name).slice(0, n0)
+            valid = np.array(want.is_valid())
+            if not np.array_equal(first[k]["validity"].astype(bool), valid):
+                raise SystemExit("bench.py: validity of column %s differs from what was written" % name)
+            w = (want.fill_null(0) if name == "val" else want).to_numpy(zero_copy_only=False)
+            got = first[k]["values"]
+            same = got.view(np.uint64)[valid].tolist() == w.view(np.uint64)[valid].tolist() if name == "x" else \
+                np.array_equal(got[valid].astype(np.int64), w[valid].astype(np.int64))
+            if not same:
+                raise SystemExit("bench.py: column %s of the first stripe differs from what was written" % name)
+        del first
+        # one context alone, nothing read ahead: where a stripe's time goes
+        feed, dec = [], []
+        for k in range(min(n_stripes, 8)):
+            cols = contexts[0].decode_stripe(md, k, read.read_stripe_footer(md, k), [1, 2, 3, 4], row_aligned=True,
+                                             device=True)
+            f_ms, d_ms = contexts[0].last_stripe_ms()
+            for c in cols:
+                c.free()
+            if k:   # (the first call grows the context's buffers)
+                feed.append(f_ms)
+                dec.append(d_ms)
+        decoded = [0]
+
+        def on_stripe(context, stripe, cols):
+            for c in cols:
+                decoded[0] += c.num_slots * (c.value_size + 1)   # values and validity, a slot per row
+                c.free()
+            return None
+
+        def one_pass():
+            return shard.decode_file_shard(contexts[0], md, 0, 1, columns=[1, 2, 3, 4], row_aligned=True,
+                                           extra_contexts=contexts[1:], device=True, on_stripe=on_stripe,
+                                           prefetch=FILE_PREFETCH)
+
+        def barrier():
+            for c in contexts:
+                c.synchronize()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+
+        for _ in range(min(args.warmup, 1)):
+            one_pass()
+        steps = max(1, min(args.steps, 3))
+        decoded[0] = 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_pass()
+        barrier()
+        elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist, device=REDUCE_DEVICE)
+        result = {
+            "metric": "end-to-end decoded GB/s of a mixed-schema ORC file (read + H2D + decode + null scatter)",
+            "value": round(decoded[0] * world / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": world,
+            "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": round(elapsed / steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+            "data": "synthetic",
+            "decoded_GBps": round(decoded[0] * world / elapsed / 1e9, 2),
+            "file_GBps": round(size * steps * world / elapsed / 1e9, 2),
+            "per_stripe_ms": {"feed": round(float(np.mean(feed)), 3) if feed else None,
+                              "decode": round(float(np.mean(dec)), 3) if dec else None,
+                              "stripes_sampled": len(dec),
+                              "note": "one context, nothing read ahead, host clock: until the stripe's bytes are "
+                                      "read and their copies queued / from then until every column is decoded"},
+            "config": {"workload": "mixed_table: pyarrow-written ORC file, uncompressed, %d rows x {int32 keys 0..15 in "
+                                   "runs of geometric length, int64 with 10%% nulls, float64, boolean} (seed 44), %d bytes "
+                                   "and %d stripes per GPU; row-aligned columns left on the device; %d contexts per GPU%s"
+                                   % (rows, size, n_stripes, FILE_CONTEXTS,
+                                      ", each reading its next stripe ahead" if FILE_PREFETCH else ""),
+                       "file_bytes_per_gpu": size, "stripes": n_stripes, "rows_per_gpu": rows,
+                       "parallelism": "stripe-sharded x%d" % world},
+        }
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = mixed_table_cpu_baseline(args, md, read, np)
+        for c in contexts:
+            c.close()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return result
+
+
+def mixed_table_cpu_baseline(args, md, read, np):
+    """The CPU oracle over the same streams, stripe after stripe for about --cpu-seconds: PRESENT ->
+    validity, DATA -> dense values per column (the pair deserialize_*_array returns,
+    tests/it/deserialize.rs:27-104; no scatter to rows)."""
+    import oracle_ctypes
+    oracle = oracle_ctypes.load()
+    t_all, decoded, rows_done, k = 0.0, 0, 0, 0
+    kinds = {1: "int", 2: "int", 3: "f64", 4: "bool"}
+    while k < len(md.stripes) and t_all < args.cpu_seconds:
+        footer = read.read_stripe_footer(md, k)
+        rows = int(md.stripes[k].number_of_rows)
+        for ci, kind in kinds.items():
+            col = read.read_stripe_column(md, k, footer, ci)
+            present = np.array(col.get_stream(0)) if col.has_stream(0) else None
+            data = np.array(col.get_stream(1))
+            t0 = time.perf_counter()
+            n = rows
+            if present is not None:
+                rc, bits, n = oracle.boolean(present, rows)
+                assert rc == 0
+            if kind == "int":
+                rc, vals, _ = oracle.rlev2(data, n, True)
+            elif kind == "f64":
+                rc, vals = oracle.floats(data, n, np.float64)
+            else:
+                rc, vals, _ = oracle.boolean(data, n)
+            assert rc == 0
+            t_all += time.perf_counter() - t0
+            decoded += n * (1 if kind == "bool" else 8) + rows
+        rows_done += rows
+        k += 1
+    return {"value": round(decoded / t_all / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "the first %d stripes (%d rows) of the same file, every stream through the oracle, single "
+                      "thread, %.1f s (streams already in memory; validity + dense values, no scatter)"
+                      % (k, rows_done, t_all)}
 
 
 def bench_zlib_file(args, rank, world, local_rank, dist, torch, np):

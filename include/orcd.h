@@ -122,6 +122,14 @@ float orcd_ctx_phase_ms(orcd_ctx *ctx, int phase);
  * The results are the same either way; this is for benchmarks and profiles. */
 enum { ORCD_PATH_GENERAL = 0, ORCD_PATH_STRIDED = 1, ORCD_PATH_PLANNED = 2 };
 int orcd_ctx_last_path(orcd_ctx *ctx);
+/* Where the time of the most recent successful orcd_decode_stripe call on this context went, by the
+ * host's clock: `feed_ms` until the bytes of the stripe's columns were read and their copies to
+ * the device queued (next to nothing when orcd_stripe_prefetch had them there already), `decode_ms`
+ * from then to the end of the call, every kernel finished -- decoding, the waits for the header
+ * totals and counts in between, and handing the arrays over.  ORCD_INVALID_ARGUMENT before the
+ * first such call.  ORCD_TRACE_STRIPE=1 in the environment prints the same and more (a line per
+ * stage and column) on stderr, with a wait for the GPU after every stage.  For benchmarks. */
+int orcd_ctx_last_stripe_ms(orcd_ctx *ctx, float *feed_ms, float *decode_ms);
 /* Text of the last HIP runtime error seen by this context (after ORCD_HIP_ERROR). */
 const char *orcd_ctx_last_hip_error(orcd_ctx *ctx);
 

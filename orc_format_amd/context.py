@@ -128,6 +128,12 @@ class Context:
         """0: the last RLE v2 decode took the general path, 1: the strided single-launch one."""
         return int(self._lib.orcd_ctx_last_path(self._h))
 
+    def last_stripe_ms(self):
+        """orcd_ctx_last_stripe_ms: (feed_ms, decode_ms) of the last decode_stripe call."""
+        feed, dec = C.c_float(), C.c_float()
+        check(self._lib.orcd_ctx_last_stripe_ms(self._h, C.byref(feed), C.byref(dec)), self._h)
+        return feed.value, dec.value
+
     # ---- host-buffer calls ------------------------------------------------------------------
     def rlev2(self, stream, num_values, signed, entry_points=None, values_per_group=0):
         """orcd_rlev2_decode, or with values_per_group orcd_rlev2_decode_groups: the entry points

@@ -313,6 +313,7 @@ struct orcd_ctx {
     // Speculative decode of regular columns (try_strided): which way the last RLE v2 call went
     // (ORCD_PATH_*), and how many eligible calls skip the attempt after it failed twice in a row.
     int last_path = 0;
+    float stripe_feed_ms = -1.0f, stripe_decode_ms = -1.0f;  // the last orcd_decode_stripe call (host clock)
     int spec_pref = ORCD_PATH_STRIDED;  // the speculative path that worked last, tried first
     uint32_t spec_fail_streak = 0, spec_skip = 0;
     bool spec_flag_clean = false;  // the device word of SLOT_SPEC_FLAG is known to be zero
@@ -613,6 +614,18 @@ int guess_entry_points(orcd_ctx *c, const uint8_t *d_stream, size_t len, int is_
 // as long as that stays a modest amount of memory; the walk of such a stream is one lane's serial
 // work (about half a microsecond per run), and staging spares the second one.
 uint32_t pick_staged_cap(uint64_t len, uint32_t n_seg) {
+    if (n_seg >= 64 && n_seg <= COOP_MAX_SEGMENTS) {
+        // A column of a file: an entry point per row group of 10 000 values, which is 20 runs of 512
+        // or 1 500 of a handful (string lengths, low-cardinality keys).  Whatever is not staged is
+        // emitted by a second walk, one lane per segment at half a microsecond a run -- 1 ms for
+        // such a segment, with a few hundred lanes on the whole chip.  So: room for every run twice
+        // the average segment's bytes can hold (a run takes two bytes at least), while that stays a
+        // modest amount of memory.
+        const uint64_t avg = len / n_seg;
+        const uint64_t cap = (std::max<uint64_t>(avg, 64) + 63) / 64 * 64;
+        if (cap * n_seg * sizeof(uint64_t) <= (256ull << 20) && cap <= 0xFFFFFF00ull)
+            return (uint32_t)std::max<uint64_t>(cap, staged_runs_cap(len, n_seg));
+    }
     if (n_seg >= 64) return staged_runs_cap(len, n_seg);
     const uint64_t cap = (len / 2 + 64) / 64 * 64;
     if (cap > 0xFFFFFF00ull || cap * n_seg * sizeof(uint64_t) > (1ull << 30)) return 0;
@@ -1167,6 +1180,13 @@ float orcd_ctx_last_elapsed_ms(orcd_ctx *c) { return orcd_ctx_phase_ms(c, 0); }
 
 int orcd_ctx_last_path(orcd_ctx *c) { return c ? c->last_path : -1; }
 
+int orcd_ctx_last_stripe_ms(orcd_ctx *c, float *feed_ms, float *decode_ms) {
+    if (!c || c->stripe_decode_ms < 0) return ORCD_INVALID_ARGUMENT;
+    if (feed_ms) *feed_ms = c->stripe_feed_ms;
+    if (decode_ms) *decode_ms = c->stripe_decode_ms;
+    return ORCD_OK;
+}
+
 const char *orcd_ctx_last_hip_error(orcd_ctx *c) {
     return c ? hipGetErrorString(c->last_hip) : "no context";
 }
@@ -1546,9 +1566,11 @@ int orcd_boolean_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_
         void *d_counts;
         ORCD_TRY(stage_in(c, SLOT_IN_B, where.data(), where.size() * sizeof(uint64_t), false, &d_where));
         ORCD_TRY(ensure(c, SLOT_TMP, plan.slice_of.size() * sizeof(uint64_t), &d_counts));
+        uint64_t largest = 0;
+        for (size_t k = 0; k < plan.slice_of.size(); k++) largest = std::max<uint64_t>(largest, slices[plan.slice_of[k]].num_values);
         HIP_TRY(c, launch_count_nonzero_slices(c->stream, d_out, (const uint64_t *)d_where,
                                                (const uint64_t *)d_where + plan.slice_of.size(),
-                                               (uint32_t)plan.slice_of.size(), (uint64_t *)d_counts));
+                                               (uint32_t)plan.slice_of.size(), (uint64_t *)d_counts, largest));
         std::vector<uint64_t> counts(plan.slice_of.size());
         HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, counts.size() * sizeof(uint64_t),
                                   hipMemcpyDeviceToHost, c->stream));
@@ -2502,7 +2524,6 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
             HIP_TRY(c, hipMemcpyAsync((int64_t *)p.offsets + rows, (int64_t *)aligned + n_values, 8,
                                       hipMemcpyDeviceToDevice, c->stream));
         }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
 
     memset(out, 0, sizeof(*out));
@@ -2515,7 +2536,9 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
     out->value_size = value_size;
     out->num_bytes = num_bytes;
     out->owner = c;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // (no wait here: arrays that stay on the device are complete when the stripe call returns --
+    // it waits for the stream once, at its end -- and a copy to the host waits for itself; blocks
+    // released in between go to work that is queued behind their last use)
     void *r;
     int rc = deliver(c, p.validity, rows, out_dev, &r);
     p.validity = nullptr;
@@ -2921,6 +2944,16 @@ int compressed_columns_to_device(orcd_ctx *c, orcd_file *file, std::vector<std::
 int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_stripe_footer *footer,
                        const uint32_t *columns, size_t n_columns, unsigned flags, orcd_column_data *out,
                        std::vector<std::unique_ptr<StripeJob>> &jobs, Pending &stripe_mem) {
+    // ORCD_TRACE_STRIPE=1: where the call's time went, a line per stripe on stderr
+    static const bool trace = [] {
+        const char *e = getenv("ORCD_TRACE_STRIPE");
+        return e && *e && *e != '0';
+    }();
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    };
+    double ms_read = 0, ms_validity = 0, ms_ints = 0;
     // 1. the bytes the columns' streams span, read once and copied once to the device
     orcd_stripe_info si;
     ORCD_TRY(orcd_file_stripe(file, stripe, &si));
@@ -3003,6 +3036,11 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
         sb.d_base = (const uint8_t *)stripe_mem.tmp;
     }
 
+    c->stripe_feed_ms = (float)since(t_start);
+    if (trace) {
+        (void)hipStreamSynchronize(c->stream);
+        ms_read = since(t_start);
+    }
     // 2. validity: the small PRESENT streams in one set of launches
     {
         StreamBatch batch;
@@ -3018,6 +3056,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
             batch.add(i, b, l, rows, ent, n_ent);
             arena_bytes += 8 * ((rows + 7) / 8);
         }
+        if (trace) fprintf(stderr, "  validity: streams and entry points gathered at %.3f ms\n", since(t_start) - ms_read);
         if (batch.slices.size() > 1) {
             const uint8_t *d_first = batch.finish();
             ORCD_TRY(dev_alloc(c, arena_bytes, &stripe_mem.tmp2));
@@ -3025,6 +3064,7 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
             const int rc = orcd_boolean_decode_batch(c, d_first, batch.hi - batch.lo, batch.slices.data(),
                                                      batch.slices.size(), (uint8_t *)stripe_mem.tmp2,
                                                      counts.data(), nullptr, ORCD_IN_DEVICE | ORCD_OUT_DEVICE);
+            if (trace) fprintf(stderr, "  validity: batch decoded at %.3f ms\n", since(t_start) - ms_read);
             if (rc == ORCD_OK) {
                 uint64_t pos = 0;
                 for (size_t k = 0; k < batch.owner.size(); k++) {
@@ -3046,6 +3086,10 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
         if ((*jobs[i]).have_validity) continue;
         const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev};
         ORCD_TRY(column_validity(c, cs, (*jobs[i]).p, &(*jobs[i]).n_values));
+    }
+    if (trace) {
+        (void)hipStreamSynchronize(c->stream);
+        ms_validity = since(t_start) - ms_read;
     }
     // 3. the small DATA streams of the integer columns in one set of launches
     {
@@ -3093,11 +3137,26 @@ int decode_stripe_impl(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
             }
         }
     }
+    if (trace) {
+        (void)hipStreamSynchronize(c->stream);
+        ms_ints = since(t_start) - ms_read - ms_validity;
+    }
     // 4. everything else, column by column
     for (size_t i = 0; i < n_columns; i++) {
         const ColumnStreams cs{file, (*jobs[i]).col, &sb, (*jobs[i]).plain_dev};
+        const double t_col = trace ? since(t_start) : 0;
         ORCD_TRY(column_values(c, cs, (*jobs[i]).type_kind, flags, (*jobs[i]).p, (*jobs[i]).n_values, (*jobs[i]).batched,
                                &out[i]));
+        if (trace && n_columns > 1) {
+            (void)hipStreamSynchronize(c->stream);
+            fprintf(stderr, "  column %u (type %d): %.3f ms\n", columns[i], (*jobs[i]).type_kind, since(t_start) - t_col);
+        }
+    }
+    if (trace) {
+        (void)hipStreamSynchronize(c->stream);
+        const double total = since(t_start);
+        fprintf(stderr, "orcd stripe %zu: %zu columns, read+copy %.3f ms, validity %.3f, integer batch %.3f, columns %.3f, total %.3f\n",
+                stripe, n_columns, ms_read, ms_validity, ms_ints, total - ms_read - ms_validity - ms_ints, total);
     }
     return ORCD_OK;
 }
@@ -3112,8 +3171,13 @@ int orcd_decode_stripe(orcd_ctx *c, orcd_file *file, size_t stripe, const orcd_s
     std::vector<std::unique_ptr<StripeJob>> jobs;
     for (size_t i = 0; i < n_columns; i++) jobs.emplace_back(new StripeJob(c));
     Pending stripe_mem(c);  // the stripe's bytes on the device, and the validity arena
+    const auto t_call = std::chrono::steady_clock::now();
+    c->stripe_feed_ms = c->stripe_decode_ms = -1.0f;
     const int rc = decode_stripe_impl(c, file, stripe, footer, columns, n_columns, flags, out, jobs, stripe_mem);
     (void)hipStreamSynchronize(c->stream);  // before the device buffers of this call are released
+    if (rc == ORCD_OK && c->stripe_feed_ms >= 0)
+        c->stripe_decode_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_call).count() -
+                              c->stripe_feed_ms;
     for (auto &j : jobs)
         if (j->col) orcd_column_free(j->col);
     if (rc != ORCD_OK)

@@ -267,7 +267,8 @@ hipError_t launch_byte_rle_emit_staged(hipStream_t st, uint32_t n_seg, const Seg
                                        const uint64_t *staged, uint32_t staged_cap, ByteRun *runs,
                                        uint32_t *win_first, uint32_t n_win_slots, uint32_t max_seg_runs);
 hipError_t launch_count_nonzero_slices(hipStream_t st, const uint8_t *bytes, const uint64_t *start,
-                                       const uint64_t *count, uint32_t n_slices, uint64_t *out);
+                                       const uint64_t *count, uint32_t n_slices, uint64_t *out,
+                                       uint64_t largest);
 // slots of win_first for a stream of total_bytes decoded bytes
 size_t byte_rle_window_slots(uint64_t total_bytes);
 hipError_t launch_byte_rle_expand(hipStream_t st, const uint8_t *stream, uint64_t len,
