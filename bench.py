@@ -249,8 +249,7 @@ def bench_rlev2(args, rank, world, local_rank, dist, torch, np):
     elapsed = time.perf_counter() - t0
     # which kernel expanded the values: the single-launch one for regular columns, or the general one
     # (the general kernel has a variant for columns with more than two runs per window)
-    value_kernel = "rlev2_strided_values_kernel" if ctx.last_path() == 1 else \
-        "rlev2_values_kernel<0, %s>" % ("true" if gen_name == "mixed_short_runs" else "false")
+    value_kernel = ctx.last_value_kernel()
     from orc_format_amd import shard
     elapsed = shard.max_over_ranks(elapsed, dist, device=REDUCE_DEVICE)
 

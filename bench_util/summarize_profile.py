@@ -26,7 +26,8 @@ import sys
 
 
 # kernels whose dominant reads are 16 bytes per lane, consecutive lanes consecutive chunks
-WIDE_READS = ("rlev2_values_kernel", "rlev2_strided_values_kernel", "string_bytes_kernel",
+WIDE_READS = ("rlev2_values_kernel", "rlev2_strided_values_kernel", "rlev2_selfplan_values_kernel",
+              "rlev2_planned_values_kernel", "string_bytes_kernel",
               "byte_rle_exits_kernel", "byte_rle_tile_kernel")
 
 

@@ -122,6 +122,11 @@ float orcd_ctx_phase_ms(orcd_ctx *ctx, int phase);
  * The results are the same either way; this is for benchmarks and profiles. */
 enum { ORCD_PATH_GENERAL = 0, ORCD_PATH_STRIDED = 1, ORCD_PATH_PLANNED = 2 };
 int orcd_ctx_last_path(orcd_ctx *ctx);
+/* Name of the kernel that expanded the values of the most recent orcd_rlev2_decode /
+ * orcd_rlev2_decode_groups call on this context, as a profiler lists it (without the orcd::
+ * namespace): the two planned ways and the two variants of the general kernel have one
+ * ORCD_PATH_* each.  A string the library owns; "" before the first call.  For benchmarks. */
+const char *orcd_ctx_last_value_kernel(orcd_ctx *ctx);
 /* Where the time of the most recent successful orcd_decode_stripe call on this context went, by the
  * host's clock: `feed_ms` until the bytes of the stripe's columns were read and their copies to
  * the device queued (next to nothing when orcd_stripe_prefetch had them there already), `decode_ms`

@@ -128,6 +128,10 @@ class Context:
         """0: the last RLE v2 decode took the general path, 1: the strided single-launch one."""
         return int(self._lib.orcd_ctx_last_path(self._h))
 
+    def last_value_kernel(self):
+        """orcd_ctx_last_value_kernel: the kernel that expanded the last RLE v2 call's values."""
+        return self._lib.orcd_ctx_last_value_kernel(self._h).decode()
+
     def last_stripe_ms(self):
         """orcd_ctx_last_stripe_ms: (feed_ms, decode_ms) of the last decode_stripe call."""
         feed, dec = C.c_float(), C.c_float()

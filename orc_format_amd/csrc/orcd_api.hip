@@ -313,6 +313,7 @@ struct orcd_ctx {
     // Speculative decode of regular columns (try_strided): which way the last RLE v2 call went
     // (ORCD_PATH_*), and how many eligible calls skip the attempt after it failed twice in a row.
     int last_path = 0;
+    const char *last_kernel = "";  // the kernel that expanded the values of the last RLE v2 call
     float stripe_feed_ms = -1.0f, stripe_decode_ms = -1.0f;  // the last orcd_decode_stripe call (host clock)
     int spec_pref = ORCD_PATH_STRIDED;  // the speculative path that worked last, tried first
     uint32_t spec_fail_streak = 0, spec_skip = 0;
@@ -816,6 +817,7 @@ int attempt_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
                                            (uint32_t)n_seg, (uint32_t)n_win, num_values, is_signed, d_out,
                                            flag, c->h_totals, stamp, stride_vals));
     mark(c, 3);  // (phases 1 and 2, header count and run table, did not run)
+    c->last_kernel = "rlev2_strided_values_kernel";
     return spec_verdict(c, stamp, done);
 }
 
@@ -846,6 +848,7 @@ int attempt_planned(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
         HIP_TRY(c, launch_rlev2_selfplan_values(c->stream, d_stream, len, d_entries, (uint32_t)n_entries, (uint32_t)n_win,
                                                 stride_vals, num_values, is_signed, d_out, flag, seg_table));
         mark(c, 3);
+        c->last_kernel = "rlev2_selfplan_values_kernel";
         const uint32_t stamp = next_stamp(c);
         HIP_TRY(c, launch_spec_publish(c->stream, flag, c->h_totals, stamp));
         ORCD_TRY(spec_verdict(c, stamp, done));
@@ -875,6 +878,7 @@ int attempt_planned(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
     t.is_signed = is_signed;
     HIP_TRY(c, launch_rlev2_planned_values(c->stream, t, d_out, flag));
     mark(c, 3);
+    c->last_kernel = "rlev2_planned_values_kernel";
     const uint32_t stamp = next_stamp(c);
     HIP_TRY(c, launch_spec_publish(c->stream, flag, c->h_totals, stamp));
     return spec_verdict(c, stamp, done);
@@ -922,6 +926,7 @@ int rlev2_device(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_va
     ORCD_TRY(rlev2_table(c, d_stream, len, num_values, d_entries, n_entries, is_signed, &t));
     HIP_TRY(c, launch_rlev2_values(c->stream, t, d_out));
     mark(c, 3);
+    c->last_kernel = rlev2_values_short_variant(t) ? "rlev2_values_kernel<0, true>" : "rlev2_values_kernel<0, false>";
     return ORCD_OK;
 }
 
@@ -1179,6 +1184,8 @@ float orcd_ctx_phase_ms(orcd_ctx *c, int phase) {
 float orcd_ctx_last_elapsed_ms(orcd_ctx *c) { return orcd_ctx_phase_ms(c, 0); }
 
 int orcd_ctx_last_path(orcd_ctx *c) { return c ? c->last_path : -1; }
+
+const char *orcd_ctx_last_value_kernel(orcd_ctx *c) { return c ? c->last_kernel : ""; }
 
 int orcd_ctx_last_stripe_ms(orcd_ctx *c, float *feed_ms, float *decode_ms) {
     if (!c || c->stripe_decode_ms < 0) return ORCD_INVALID_ARGUMENT;

@@ -200,6 +200,8 @@ hipError_t launch_rlev2_resync(hipStream_t st, const uint8_t *stream, uint64_t l
 // abort_flag (nullable): a device word; when it is not zero as the kernel starts, nothing is decoded
 hipError_t launch_rlev2_values(hipStream_t st, const Rlev2Table &t, int64_t *out,
                                const uint32_t *abort_flag = nullptr);
+// (which of its two variants that launches: the one for columns of more than two runs per window)
+bool rlev2_values_short_variant(const Rlev2Table &t);
 // The same behind a plan of the column: every window of t.group_run is one run (t.runs and
 // t.group_first are not looked at).
 hipError_t launch_rlev2_planned_values(hipStream_t st, const Rlev2Table &t, int64_t *out,

@@ -2928,6 +2928,8 @@ hipError_t launch_seg_value_offsets(hipStream_t st, const SegTable &t, const uin
     return hipGetLastError();
 }
 
+bool rlev2_values_short_variant(const Rlev2Table &t) { return (uint64_t)t.n_runs > 2ull * t.n_groups; }
+
 template <int MODE>
 static hipError_t launch_values_mode(hipStream_t st, const Rlev2Table &t, int64_t *out,
                                      uint64_t *group_sums, uint32_t *flags) {
@@ -2937,7 +2939,7 @@ static hipError_t launch_values_mode(hipStream_t st, const Rlev2Table &t, int64_
     // writes values, gives a wavefront two windows)
     const uint32_t pairs = (t.n_groups + 1) / 2;
     const uint32_t short_blocks = MODE == MODE_VALUES ? (pairs + VAL_WAVES - 1) / VAL_WAVES : blocks;
-    if ((uint64_t)t.n_runs > 2ull * t.n_groups)
+    if (rlev2_values_short_variant(t))
         rlev2_values_kernel<MODE, true><<<short_blocks, VAL_WAVES * 64, 0, st>>>(
             t.stream, t.len, t.runs, t.group_first, t.group_run, t.n_groups, t.n_runs, t.num_values,
             t.is_signed, out, group_sums, flags);
