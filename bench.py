@@ -160,6 +160,22 @@ def main():
                 result["workloads"]["zlib_file"]["workload"] = r["config"]["workload"]
             except Exception as e:  # noqa: BLE001
                 result["workloads"]["zlib_file"] = {"skipped": "%s: %s" % (type(e).__name__, e)}
+    if args.workload == "direct_w17" and world > 1 and explicit_rows is None and not args.headline_only:
+        # the feed path on every rank at once: each rank reads and decodes a file of its own, so the
+        # first run on a whole node shows at once what the ranks' readers, copy threads and PCIe
+        # links do to each other (per_rank_file_GBps; the helper threads of each rank come out of
+        # its share of the host's CPUs, orcd_helper_threads)
+        sub = argparse.Namespace(**vars(args))
+        sub.rows, sub.steps, sub.warmup = None, min(args.steps, 3), 1
+        r = run_workload(sub, "strings_file", rank, world, local_rank, dist, torch, np)
+        import ctypes as C
+        from orc_format_amd import _native
+        budget, peak = C.c_int(), C.c_int()
+        _native.lib().orcd_helper_threads(C.byref(budget), None, C.byref(peak))
+        result["strings_file"] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "decoded_GBps",
+                                                    "per_rank_file_GBps")}
+        result["strings_file"]["helper_threads_rank0"] = {"budget": budget.value, "peak": peak.value}
+        result["strings_file"]["workload"] = r["config"]["workload"]
     if rank == 0:
         if rehearsal:
             result["rehearsal"] = "ranks shared one GPU over gloo: not a measurement"
@@ -515,8 +531,11 @@ def bench_strings_file(args, rank, world, local_rank, dist, torch, np):
         t0 = time.perf_counter()
         for _ in range(steps):
             res = one_pass()
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0   # this rank's own passes, before it waits for the others
         barrier()
         elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist, device=REDUCE_DEVICE)
+        per_rank = [round(size * steps / t / 1e9, 2) for t in shard.gather_over_ranks(own, dist, device=REDUCE_DEVICE)]
         for _, _, (stripe, offsets, num_bytes) in res:
             w = want[stripe % len(want)]
             if num_bytes != int(w[-1]) or not np.array_equal(offsets, w):
@@ -532,6 +551,7 @@ def bench_strings_file(args, rank, world, local_rank, dist, torch, np):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic",
         "decoded_GBps": round(decoded[0] * world / elapsed / 1e9, 2),
+        "per_rank_file_GBps": per_rank,
         "config": {"workload": "strings_file: uncompressed ORC file of %d stripes x %d strings, lengths "
                                "U[8,56] as RLE v2 Direct width 6, ASCII DATA (seed 46), %d bytes per GPU; "
                                "%d contexts per GPU%s" % (n_stripes, FILE_STRINGS_PER_STRIPE, size, FILE_CONTEXTS,

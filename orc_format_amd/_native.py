@@ -68,6 +68,7 @@ SIGNATURES = {
     "orcd_ctx_last_hip_error": (C.c_char_p, [P]),
     "orcd_ctx_last_path": (C.c_int, [P]),
     "orcd_ctx_last_value_kernel": (C.c_char_p, [P]),
+    "orcd_helper_threads": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "orcd_ctx_last_stripe_ms": (C.c_int, [P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "orcd_rlev2_decode": (C.c_int, [P, P, SZ, SZ, U64P, SZ, P, C.c_uint]),
     "orcd_rlev2_decode_groups": (C.c_int, [P, P, SZ, SZ, U64P, SZ, C.c_uint64, P, C.c_uint]),

@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <sched.h>
+#include <pthread.h>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -118,6 +120,8 @@ struct BlockCache {
 // The host threads of a context that move large transfers (see run_chunked): started on first
 // use, parked between transfers, joined when the context is destroyed.
 struct CopyThreads {
+    cpu_set_t bind;          // the CPUs next to the device's memory (see orcd_internal_numa_cpus)
+    bool have_bind = false;
     std::vector<std::thread> threads;  // thread k serves as worker k + 1; the caller is worker 0
     std::mutex m;
     std::condition_variable wake, done;
@@ -127,6 +131,7 @@ struct CopyThreads {
     bool stop = false;
 
     void serve(int t) {
+        if (have_bind) (void)pthread_setaffinity_np(pthread_self(), sizeof(bind), &bind);  // (best effort)
         uint64_t seen = 0;
         for (;;) {
             std::function<void(int)> fn;
@@ -312,6 +317,8 @@ struct orcd_ctx {
     hipError_t last_hip = hipSuccess;
     // Speculative decode of regular columns (try_strided): which way the last RLE v2 call went
     // (ORCD_PATH_*), and how many eligible calls skip the attempt after it failed twice in a row.
+    cpu_set_t numa_cpus;           // CPUs of the NUMA node the device hangs off, for the helper threads
+    bool have_numa_cpus = false;
     int last_path = 0;
     const char *last_kernel = "";  // the kernel that expanded the values of the last RLE v2 call
     float stripe_feed_ms = -1.0f, stripe_decode_ms = -1.0f;  // the last orcd_decode_stripe call (host clock)
@@ -389,8 +396,20 @@ int run_chunked(orcd_ctx *c, StageSet &ss, uint64_t len, Step step) {
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, CHUNK_MIN), STAGE_CHUNK);
     const uint64_t n_chunks = (len + chunk - 1) / chunk;
     int n_threads = (int)std::min<uint64_t>(N_READERS, n_chunks);
+    // (the helpers beside this thread come out of the process's budget, orcd_helper_threads)
+    struct Lease {
+        int n;
+        ~Lease() { orcd_internal_helpers_release(n); }
+    } lease{n_threads > 1 ? orcd_internal_helpers_lease(n_threads - 1) : 0};
+    n_threads = 1 + lease.n;
     if (n_threads > 1) {
-        if (!ss.copy_threads) ss.copy_threads = new (std::nothrow) CopyThreads();
+        if (!ss.copy_threads) {
+            ss.copy_threads = new (std::nothrow) CopyThreads();
+            if (ss.copy_threads && c->have_numa_cpus) {
+                ss.copy_threads->bind = c->numa_cpus;
+                ss.copy_threads->have_bind = true;
+            }
+        }
         n_threads = ss.copy_threads ? std::min(n_threads, ss.copy_threads->ensure(n_threads - 1) + 1) : 1;
     }
     std::atomic<int> status{ORCD_OK};
@@ -1097,6 +1116,11 @@ int orcd_ctx_create(int device_id, orcd_ctx **out) try {
         return ORCD_HIP_ERROR;
     }
     c->stream = c->own_stream;
+    {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device_id) == hipSuccess)
+            c->have_numa_cpus = orcd_internal_numa_cpus(bus, &c->numa_cpus, sizeof(c->numa_cpus)) != 0;
+    }
     *out = c;
     return ORCD_OK;
 } ORCD_CATCH
@@ -2159,13 +2183,17 @@ constexpr uint64_t PINNED_READ_MIN = 4u << 20;  // smaller regions are read the 
 int read_in_slices(orcd_file *file, uint64_t off, uint64_t len, uint8_t *dst) {
     const uint64_t slice = ((len + PINNED_READERS - 1) / PINNED_READERS + 4095) & ~(uint64_t)4095;
     int status[PINNED_READERS];
+    for (int i = 0; i < PINNED_READERS; i++) status[i] = -1;  // -1: nobody has read this slice yet
     std::vector<std::thread> threads;
     auto work = [&](int i) {
         const uint64_t lo = std::min<uint64_t>(len, (uint64_t)i * slice), hi = std::min<uint64_t>(len, lo + slice);
         status[i] = hi > lo ? orcd_file_read_at(file, off + lo, hi - lo, dst + lo) : ORCD_OK;
     };
-    for (int i = 1; i < PINNED_READERS; i++) {
-        status[i] = -1;
+    struct Lease {
+        int n;
+        ~Lease() { orcd_internal_helpers_release(n); }
+    } lease{orcd_internal_helpers_lease(PINNED_READERS - 1)};
+    for (int i = 1; i <= lease.n; i++) {
         try {
             threads.emplace_back(work, i);
         } catch (...) {
@@ -2664,7 +2692,9 @@ std::vector<char> split_for_host(const std::vector<orcd_chunk> &work) {
     std::vector<size_t> order(work.size());
     for (size_t k = 0; k < order.size(); k++) order[k] = k;
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return work[a].src_length > work[b].src_length; });
-    const unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    int budget = 1;
+    (void)orcd_helper_threads(&budget, nullptr, nullptr);
+    const unsigned threads = (unsigned)std::min(16, std::max(1, budget));
     double gpu_bytes = 0, host_us = 0;
     for (const orcd_chunk &w : work) gpu_bytes += w.src_length;
     // largest first: the host takes a chunk as long as it still ends before the GPU would

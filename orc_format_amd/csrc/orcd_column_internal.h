@@ -40,3 +40,14 @@ struct orcd_internal_host_chunk {
 };
 extern "C" int orcd_internal_inflate_list(int codec, const orcd_internal_host_chunk *list, size_t n, uint8_t *out,
                                           size_t pitch, uint32_t *sizes);
+
+// Helper threads -- the readers and copiers of a stripe's bytes, the host's decompression threads --
+// come out of one budget for the whole process (orcd_helper_threads): an operation asks for as many
+// as it could use beside the calling thread, gets what is left of the budget (possibly none: the
+// caller then does the work alone), and gives them back when it is done.
+extern "C" int orcd_internal_helpers_lease(int want);
+extern "C" void orcd_internal_helpers_release(int n);
+// The CPUs of the NUMA node device memory at PCI address `pci_bus_id` is attached to, as a
+// cpu_set_t the helpers of that device's contexts bind themselves to; false when the system does
+// not say (one node, no sysfs entry) or ORCD_NUMA_BIND=0.
+extern "C" int orcd_internal_numa_cpus(const char *pci_bus_id, void *cpu_set, size_t cpu_set_bytes);

@@ -3,6 +3,7 @@
 // Mirrors read_metadata / read_stripe_footer / read_stripe_column / Column of the orc-format crate
 // (src/read/mod.rs:46-159, src/read/column.rs:11-79) with a hand-written reader for the handful of
 // protobuf messages involved (src/proto.rs:89-99, 113-164, 166-217, 236-278).  No GPU code here.
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <unistd.h>
@@ -361,6 +362,38 @@ int inflate_one(const uint8_t *src, size_t len, uint64_t block, std::vector<uint
 constexpr size_t INFLATE_PARALLEL_MIN = 1u << 20;
 constexpr unsigned INFLATE_MAX_THREADS = 16;
 
+// ---- the process's budget of helper threads ------------------------------------------------------
+// A context starts up to 8 copy threads, a read-ahead thread with readers of its own, 4 readers per
+// compressed stripe and up to 16 decompression threads; a rank may hold several contexts and a node
+// runs a rank per GPU.  Left alone that is hundreds of threads on a host of a few dozen cores, all
+// of them wanted at the same moments.  The budget: ORCD_HELPER_THREADS when set, else the CPUs this
+// process may use (OMP_NUM_THREADS where a launcher set it, else the hardware's) shared out over
+// the ranks of the node (LOCAL_WORLD_SIZE, else WORLD_SIZE), at least 2 and at most 64.
+struct HelperBudget {
+    int budget;
+    std::atomic<int> in_use{0}, peak{0};
+    HelperBudget() {
+        auto env_int = [](const char *name) {
+            const char *e = getenv(name);
+            return e && *e ? atoi(e) : 0;
+        };
+        int b = env_int("ORCD_HELPER_THREADS");
+        if (b <= 0) {
+            int cpus = env_int("OMP_NUM_THREADS");
+            if (cpus <= 0) cpus = (int)std::max(1u, std::thread::hardware_concurrency());
+            int ranks = env_int("LOCAL_WORLD_SIZE");
+            if (ranks <= 0) ranks = env_int("WORLD_SIZE");
+            if (ranks <= 0) ranks = 1;
+            b = std::max(2, cpus / ranks);
+        }
+        budget = std::min(std::max(b, 1), 64);
+    }
+};
+HelperBudget &helper_budget() {
+    static HelperBudget b;
+    return b;
+}
+
 int decompress_one(int codec, const uint8_t *src, size_t len, uint64_t block, std::vector<uint8_t> &out) {
     switch (codec) {
     case COMP_ZLIB: return inflate_one(src, len, block, out);
@@ -396,9 +429,15 @@ int inflate_chunks(int codec, const uint8_t *src, size_t n, uint64_t block, std:
     if (const char *e = getenv("ORCD_INFLATE_PARALLEL_MIN"))  // (tests: the threaded way on small files)
         if (*e) parallel_min = (size_t)strtoull(e, nullptr, 10);
     if (compressed_bytes >= parallel_min && list.size() > 1) {
-        n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), INFLATE_MAX_THREADS);
-        n_threads = (unsigned)std::min<size_t>(n_threads, list.size());
+        n_threads = (unsigned)std::min<size_t>(INFLATE_MAX_THREADS, list.size());
     }
+    // (the helpers beside this thread come out of the process's budget)
+    const int leased = n_threads > 1 ? orcd_internal_helpers_lease((int)n_threads - 1) : 0;
+    struct Lease {
+        int n;
+        ~Lease() { orcd_internal_helpers_release(n); }
+    } lease{leased};
+    n_threads = 1 + (unsigned)leased;
     if (n_threads <= 1) {
         for (const Chunk &c : list) {
             if (chunks) chunks->push_back({(uint64_t)c.header, (uint64_t)(out.size() - out0)});
@@ -476,8 +515,13 @@ extern "C" int orcd_internal_inflate_list(int codec, const orcd_internal_host_ch
             }
         }
     };
-    unsigned n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), INFLATE_MAX_THREADS);
-    n_threads = (unsigned)std::min<size_t>(n_threads, std::max<size_t>(n, 1));
+    unsigned n_threads = (unsigned)std::min<size_t>(INFLATE_MAX_THREADS, std::max<size_t>(n, 1));
+    const int leased = n_threads > 1 ? orcd_internal_helpers_lease((int)n_threads - 1) : 0;
+    struct Lease {
+        int n;
+        ~Lease() { orcd_internal_helpers_release(n); }
+    } lease{leased};
+    n_threads = 1 + (unsigned)leased;
     std::vector<std::thread> threads;
     for (unsigned i = 1; i < n_threads; i++) {
         try {
@@ -1180,6 +1224,77 @@ int orcd_column_entry_points(orcd_file *f, orcd_column *col, int kind, const uin
     *n_entries = col->entries[kind].size();
     return ORCD_OK;
 } ORCD_CATCH
+
+int orcd_internal_helpers_lease(int want) {
+    if (want <= 0) return 0;
+    HelperBudget &b = helper_budget();
+    int cur = b.in_use.load();
+    for (;;) {
+        const int got = std::min(want, std::max(0, b.budget - cur));
+        if (got == 0) return 0;
+        if (b.in_use.compare_exchange_weak(cur, cur + got)) {
+            int p = b.peak.load();
+            while (p < cur + got && !b.peak.compare_exchange_weak(p, cur + got)) {
+            }
+            return got;
+        }
+    }
+}
+
+void orcd_internal_helpers_release(int n) {
+    if (n > 0) helper_budget().in_use.fetch_sub(n);
+}
+
+int orcd_helper_threads(int *budget, int *in_use, int *peak) {
+    HelperBudget &b = helper_budget();
+    if (budget) *budget = b.budget;
+    if (in_use) *in_use = b.in_use.load();
+    if (peak) *peak = b.peak.load();
+    return ORCD_OK;
+}
+
+int orcd_internal_numa_cpus(const char *pci_bus_id, void *cpu_set, size_t cpu_set_bytes) {
+    if (!pci_bus_id || !cpu_set || cpu_set_bytes < sizeof(cpu_set_t)) return 0;
+    if (const char *e = getenv("ORCD_NUMA_BIND"))
+        if (*e == '0') return 0;
+    char path[256], line[4096];
+    std::string id(pci_bus_id);
+    for (auto &ch : id) ch = (char)tolower((unsigned char)ch);
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", id.c_str());
+    FILE *fp = fopen(path, "r");
+    if (!fp) return 0;
+    int node = -1;
+    const int got = fscanf(fp, "%d", &node);
+    fclose(fp);
+    if (got != 1 || node < 0) return 0;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    fp = fopen(path, "r");
+    if (!fp) return 0;
+    const bool have = fgets(line, sizeof(line), fp) != nullptr;
+    fclose(fp);
+    if (!have) return 0;
+    cpu_set_t *set = (cpu_set_t *)cpu_set;
+    CPU_ZERO(set);
+    int n_cpus = 0;
+    for (char *p = line; *p;) {  // "0-47,96-143"
+        char *end;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long k = a; k <= b && k < CPU_SETSIZE; k++) {
+            CPU_SET((int)k, set);
+            n_cpus++;
+        }
+        if (*p == ',') p++;
+        else break;
+    }
+    return n_cpus > 0;
+}
 
 uint64_t orcd_column_values_per_group(orcd_file *f, orcd_column *col, int kind) try {
     const uint64_t *e;

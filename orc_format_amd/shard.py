@@ -48,6 +48,18 @@ def max_over_ranks(value, dist=None, device=None):
     return float(t.item())
 
 
+def gather_over_ranks(value, dist=None, device=None):
+    """The ranks' values of a float, in rank order (every rank gets the list)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    import torch
+    n, r = dist.get_world_size(), dist.get_rank()
+    t = torch.zeros(n, dtype=torch.float64, device=device or "cpu")
+    t[r] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
 def sum_over_ranks(value, dist=None, device=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)

@@ -153,6 +153,7 @@ extern "C" {
     pub fn orcd_ctx_last_path(ctx: *mut orcd_ctx) -> c_int;
     pub fn orcd_ctx_last_value_kernel(ctx: *mut orcd_ctx) -> *const c_char;
     pub fn orcd_ctx_last_stripe_ms(ctx: *mut orcd_ctx, feed_ms: *mut f32, decode_ms: *mut f32) -> c_int;
+    pub fn orcd_helper_threads(budget: *mut c_int, in_use: *mut c_int, peak: *mut c_int) -> c_int;
     pub fn orcd_ctx_last_hip_error(ctx: *mut orcd_ctx) -> *const c_char;
     pub fn orcd_rlev2_decode(ctx: *mut orcd_ctx, stream: *const u8, len: usize, num_values: usize,
                              entry_points: *const u64, n_entries: usize, out: *mut i64,

@@ -154,3 +154,66 @@ def test_decode_file_shard_keeps_a_context_on_one_thread(golden_dir):
     with pytest.raises(RuntimeError):
         shard.decode_file_shard(_ExclusiveContext(delays), md, 0, 1, columns=[1],
                                 extra_contexts=[Failing(delays)])
+
+
+def _helper_budget_probe(path):
+    """Child process body: reads the columns of a zlib file from several threads at once and reports
+    the helper budget, the peak of helpers at work at once, and whether the bytes were the same as a
+    single-threaded read's."""
+    return r'''
+import ctypes as C, os, sys, threading
+sys.path.insert(0, %r)
+from orc_format_amd import _native as N, read
+lib = N.lib()
+path = %r
+
+def streams():
+    md = read.read_metadata(path)
+    out = []
+    for si in range(len(md.stripes)):
+        ft = read.read_stripe_footer(md, si)
+        for ci in (1, 2):
+            col = read.read_stripe_column(md, si, ft, ci)
+            out.append(bytes(col.get_stream(1)))
+    return out
+
+got = [None] * 6
+ths = [threading.Thread(target=lambda k=k: got.__setitem__(k, streams())) for k in range(6)]
+for t in ths: t.start()
+for t in ths: t.join()
+b, u, p = C.c_int(), C.c_int(), C.c_int()
+lib.orcd_helper_threads(C.byref(b), C.byref(u), C.byref(p))
+print(b.value, u.value, p.value, int(all(g == got[0] for g in got)))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)
+
+
+@pytest.mark.parametrize("env,want_budget", [
+    ({"ORCD_HELPER_THREADS": "3"}, 3),
+    ({"OMP_NUM_THREADS": "16", "LOCAL_WORLD_SIZE": "8"}, 2),
+    ({"OMP_NUM_THREADS": "16", "WORLD_SIZE": "2"}, 8),
+    ({"ORCD_HELPER_THREADS": "1"}, 1),
+])
+def test_helper_threads_stay_within_the_process_budget(tmp_path, env, want_budget):
+    """Six threads decompress a zlib file's chunks at once (every chunk list would take up to 16
+    threads of its own): the helpers at work never exceed the budget -- the one number an 8-rank
+    node sets per process -- and nothing is left leased afterwards."""
+    import subprocess
+    import sys
+    pa = pytest.importorskip("pyarrow")
+    orc = pytest.importorskip("pyarrow.orc")
+    rng = np.random.default_rng(3)
+    path = os.path.join(tmp_path, "chunks.orc")
+    orc.write_table(pa.table({"a": pa.array(rng.integers(0, 2**40, size=400_000)),
+                              "b": pa.array(rng.standard_normal(400_000))}),
+                    path, compression="zlib", compression_block_size=65536)
+    full = dict(os.environ, ORCD_INFLATE_PARALLEL_MIN="1")
+    for k in ("ORCD_HELPER_THREADS", "OMP_NUM_THREADS", "LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        full.pop(k, None)
+    full.update(env)
+    out = subprocess.run([sys.executable, "-c", _helper_budget_probe(path)], env=full, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    budget, in_use, peak, same = map(int, out.stdout.split())
+    assert budget == want_budget
+    assert in_use == 0 and 1 <= peak <= budget
+    assert same == 1
