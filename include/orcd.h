@@ -162,7 +162,11 @@ const char *orcd_ctx_last_hip_error(orcd_ctx *ctx);
  * starts -- for instance the stream positions of the column's ROW_INDEX entries.  They only add
  * parallelism to the header scan (one lane walks the headers between two consecutive entries).
  * The first entry is taken to be offset 0 whatever its value.  An entry that is not a run
- * boundary yields ORCD_OUT_OF_SPEC. */
+ * boundary yields ORCD_OUT_OF_SPEC.
+ *
+ * After any error return the contents of out[] are undefined: the paths that decode a regular
+ * column without a header scan (orcd_ctx_last_path) write as they verify, and what an attempt that
+ * did not hold has written is overwritten only when the general path then succeeds. */
 int orcd_rlev2_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t num_values,
                       const uint64_t *entry_points, size_t n_entries, int64_t *out,
                       unsigned flags);
@@ -193,7 +197,9 @@ int orcd_rlev2_decode_groups(orcd_ctx *ctx, const uint8_t *stream, size_t len, s
  * not inflate).  sizes[k] (host memory) receives the bytes chunk k decompressed to, or 0xFFFFFFFF;
  * the call returns ORCD_DECOMPRESSION when any chunk does not inflate -- the same chunks as zlib
  * refuses -- and the chunks that did are in dst all the same.  Flags: ORCD_IN_DEVICE (src), ORCD_OUT_DEVICE (dst); `chunks` and `sizes` are host
- * memory.  The places in dst must not overlap. */
+ * memory.  The places in dst must not overlap.  The kernel reads src in whole aligned 16-byte
+ * words: with ORCD_IN_DEVICE up to 15 bytes in front of src and behind src + src_len are read
+ * (never used, and never across a page that src itself does not touch). */
 typedef struct {
     uint64_t src_offset;
     uint64_t dst_offset;
@@ -215,8 +221,10 @@ int orcd_rlev1_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t n
                       unsigned flags);
 
 /* orcd_rlev2_decode without any allocation.  No counterpart in the crate: this is for callers that
- * cannot allocate device memory at the point of the call -- code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc.  `stream`, `entry_points` and `out` are DEVICE
+ * cannot allocate device memory at the point of the call -- tight serving loops, harnesses that
+ * forbid hipMalloc.  It allocates nothing, but it does wait for its stream: the host reads the
+ * header totals (and the verdict of the single-launch attempt) back before it launches the rest,
+ * so it cannot run under HIP graph capture.  `stream`, `entry_points` and `out` are DEVICE
  * pointers (the ORCD_IN_DEVICE / ORCD_OUT_DEVICE / ORCD_ENTRIES_HOST flags are not consulted; only
  * ORCD_SIGNED is), the results are those of orcd_rlev2_decode, and everything the kernels keep
  * beside input and output lives in a static device array of the library (under 8 MiB, held by every
@@ -227,7 +235,9 @@ int orcd_rlev1_decode(orcd_ctx *ctx, const uint8_t *stream, size_t len, size_t n
  *   ORCD_NOALLOC_MAX_RUNS runs.
  * A long stream without entry points is walked serially (the entry-point guesser of
  * orcd_rlev2_decode allocates).  All calls on one GPU share the one array, whatever their context:
- * calls that overlap in time on one GPU race and must be serialized by the caller. */
+ * calls that overlap in time on one GPU race and must be serialized by the caller.
+ * As for every decode call: after an error return the contents of out[] are undefined (an attempt
+ * at the single-launch path that did not hold may have written part of it). */
 enum {
     ORCD_NOALLOC_MAX_VALUES = 16777216, /* 2^24 */
     ORCD_NOALLOC_MAX_ENTRIES = 65536,

@@ -1322,10 +1322,24 @@ int orcd_inflate_chunks(orcd_ctx *c, const uint8_t *src, size_t src_len, const o
     const int rc = inflate_device(c, (const uint8_t *)d_src, src_len, chunks, n_chunks, d_dst, dst_len, sizes);
     mark(c, 3);
     if (rc != ORCD_OK && rc != ORCD_DECOMPRESSION) return rc;
-    if (!out_dev)  // (only the bytes that were written: the rest of the staging block is not the caller's)
-        for (size_t k = 0; k < n_chunks; k++)
-            if (sizes[k] && sizes[k] != 0xFFFFFFFFu) HIP_TRY(c, hipMemcpyAsync(dst + chunks[k].dst_offset, d_dst + chunks[k].dst_offset, sizes[k],
-                                                    hipMemcpyDeviceToHost, c->stream));
+    if (!out_dev) {
+        // only the bytes that were written (the rest of the staging block is not the caller's), and
+        // chunks that fill their places and follow one another -- all but the last of a stream, as
+        // the writers make them -- in one copy: a stripe has thousands of chunks, and a copy to
+        // pageable memory is staged by the runtime one at a time
+        for (size_t k = 0; k < n_chunks;) {
+            if (!sizes[k] || sizes[k] == 0xFFFFFFFFu) {
+                k++;
+                continue;
+            }
+            const uint64_t from = chunks[k].dst_offset;
+            uint64_t to = from + sizes[k];
+            size_t j = k + 1;
+            while (j < n_chunks && sizes[j] && sizes[j] != 0xFFFFFFFFu && chunks[j].dst_offset == to) to += sizes[j++];
+            HIP_TRY(c, hipMemcpyAsync(dst + from, d_dst + from, to - from, hipMemcpyDeviceToHost, c->stream));
+            k = j;
+        }
+    }
     if (!out_dev) HIP_TRY(c, hipStreamSynchronize(c->stream));
     return rc;
 } ORCD_CATCH

@@ -299,30 +299,45 @@ int snappy_one(const uint8_t *src, size_t len, uint64_t block, std::vector<uint8
 }
 
 // One LZ4 block / one Zstandard frame: neither says in ORC how large it gets, but none may exceed
-// the file's compression block size.
+// the file's compression block size.  The block size is the file's word (up to a gigabyte) and a
+// chunk may be a few bytes, so the room is not zero-filled at that size for every chunk: a first
+// try gets sixteen times the chunk's size (at least 64 KiB), and only a chunk that does not fit
+// that -- or does not decode at all, which the libraries do not tell apart -- gets the whole block.
+template <typename Try>
+int grow_and_decode(size_t len, uint64_t block, std::vector<uint8_t> &out, Try attempt) {
+    const size_t at = out.size();
+    uint64_t room = std::min<uint64_t>(block, std::max<uint64_t>(64u << 10, (uint64_t)len * 16));
+    for (;;) {
+        out.resize(at + room);
+        size_t got = 0;
+        if (attempt(out.data() + at, (size_t)room, &got)) {
+            out.resize(at + got);
+            return ORCD_OK;
+        }
+        if (room >= block) break;
+        room = block;
+    }
+    out.resize(at);
+    return ORCD_DECOMPRESSION;
+}
+
 int lz4_one(const uint8_t *src, size_t len, uint64_t block, std::vector<uint8_t> &out) {
     if (len > 0x7FFFFFFFull || block > 0x7FFFFFFFull) return ORCD_DECOMPRESSION;
-    const size_t at = out.size();
-    out.resize(at + block);
-    const int got = codec_libs().lz4_decompress_safe((const char *)src, (char *)out.data() + at, (int)len, (int)block);
-    if (got < 0) {
-        out.resize(at);
-        return ORCD_DECOMPRESSION;
-    }
-    out.resize(at + (size_t)got);
-    return ORCD_OK;
+    return grow_and_decode(len, block, out, [&](uint8_t *dst, size_t room, size_t *got) {
+        const int n = codec_libs().lz4_decompress_safe((const char *)src, (char *)dst, (int)len, (int)room);
+        if (n < 0) return false;
+        *got = (size_t)n;
+        return true;
+    });
 }
 
 int zstd_one(const uint8_t *src, size_t len, uint64_t block, std::vector<uint8_t> &out) {
-    const size_t at = out.size();
-    out.resize(at + block);
-    const size_t got = codec_libs().zstd_decompress(out.data() + at, block, src, len);
-    if (codec_libs().zstd_is_error(got)) {
-        out.resize(at);
-        return ORCD_DECOMPRESSION;
-    }
-    out.resize(at + got);
-    return ORCD_OK;
+    return grow_and_decode(len, block, out, [&](uint8_t *dst, size_t room, size_t *got) {
+        const size_t n = codec_libs().zstd_decompress(dst, room, src, len);
+        if (codec_libs().zstd_is_error(n)) return false;
+        *got = n;
+        return true;
+    });
 }
 
 // One compressed chunk (raw deflate, src[0, len)) appended to `out`; it may not grow past `block`.

@@ -110,3 +110,44 @@ def test_noalloc_more_runs_than_the_table_holds():
         ctx.rlev2_device(d_stream.data_ptr(), d_stream.numel(), 3 * n_runs, False, out.data_ptr())
         ctx.synchronize()
         assert bool((out == 5).all())
+
+
+def test_noalloc_allocates_nothing(oracle):
+    """What the entry point is for: on a context that has decoded nothing yet -- its buffers are all
+    unallocated -- the device's free memory is the same after the calls as before, on the path with
+    the header scan and on the single-launch path."""
+    import torch
+    from orc_format_amd import Context
+    rng = np.random.default_rng(99)
+    irregular, irr_vals, irr_starts = enc.random_stream(rng, 3000, True)
+    parts, vals, starts, pos = [], [], [], 0
+    for r in range(200):
+        v = rng.integers(-(1 << 15), 1 << 15, size=512, dtype=np.int64)
+        b = enc.direct(v, 17, True)
+        starts.append(pos)
+        pos += len(b)
+        parts.append(b)
+        vals.append(v)
+    regular, reg_vals = b"".join(parts), np.concatenate(vals)
+    cases = []
+    for stream, want, ent in ((irregular, irr_vals, irr_starts[::40]), (regular, reg_vals, starts[::20])):
+        d_stream = _device(torch, stream)
+        d_ent = torch.from_numpy(np.asarray(ent, dtype=np.uint64).view(np.int64).copy()).cuda()
+        out = torch.zeros(want.size, dtype=torch.int64, device="cuda")
+        cases.append((d_stream, d_ent, out, want))
+    with Context(0) as ctx:
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        paths = []
+        for _ in range(2):
+            for d_stream, d_ent, out, want in cases:
+                ctx.rlev2_device_noalloc(d_stream.data_ptr(), d_stream.numel(), want.size, True, out.data_ptr(),
+                                         d_ent.data_ptr(), d_ent.numel())
+                paths.append(ctx.last_path())
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        free_after = torch.cuda.mem_get_info()[0]
+        assert free_after == free_before, (free_before, free_after)
+        assert paths[:2] == [0, 1]
+        for d_stream, d_ent, out, want in cases:
+            assert (out.cpu().numpy() == want).all()
