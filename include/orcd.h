@@ -92,7 +92,7 @@ int orcd_ctx_synchronize(orcd_ctx *ctx);
 int orcd_ctx_release_cached(orcd_ctx *ctx);
 /* How many bytes of released result arrays and temporaries of the column calls the context keeps
  * for its next calls instead of handing them back to the runtime: device memory, and pinned host
- * memory (defaults 64 GiB and 32 GiB; 0 keeps nothing).  Takes effect from the next release on;
+ * memory (defaults 16 GiB and 8 GiB per context; 0 keeps nothing).  Takes effect from the next release on;
  * orcd_ctx_release_cached empties what is held now. */
 int orcd_ctx_set_cache_limit(orcd_ctx *ctx, size_t device_bytes, size_t host_bytes);
 /* Copies `bytes` bytes from device memory -- typically one array of an orcd_column_data that was

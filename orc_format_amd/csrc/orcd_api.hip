@@ -313,7 +313,7 @@ struct orcd_ctx {
     BlockCache dev_cache{false};   // device memory
     BlockCache host_cache{true};   // pinned host memory: host results of the column calls
     // beyond these, released blocks go back to the runtime (orcd_ctx_set_cache_limit)
-    size_t dev_cache_limit = 64ull << 30, host_cache_limit = 32ull << 30;
+    size_t dev_cache_limit = 16ull << 30, host_cache_limit = 8ull << 30;  // (orcd_ctx_set_cache_limit)
     hipError_t last_hip = hipSuccess;
     // Speculative decode of regular columns (try_strided): which way the last RLE v2 call went
     // (ORCD_PATH_*), and how many eligible calls skip the attempt after it failed twice in a row.
