@@ -11,6 +11,6 @@ for wl in "$@"; do
 import json, sys
 tag, wl = sys.argv[1:3]
 d = json.load(open("gpurun_out/ab_%s_%s.json" % (tag, wl)))
-print(tag, wl, "step", d["ms_per_step"], "decoded", d["decoded_frac_of_hbm_peak"], d["phases_ms"], d["roofline"]["kernel"], d["roofline"]["frac"], flush=True)
+print(tag, wl, "step", d["ms_per_step"], "decoded", d.get("decoded_frac_of_hbm_peak"), d.get("phases_ms"), d.get("value"), (d.get("roofline") or {}).get("kernel"), (d.get("roofline") or {}).get("frac"), flush=True)
 PY
 done

@@ -65,15 +65,19 @@ def patched_base(ctx):
 
 
 def dictionary(ctx):
-    """10^8 indices into a dictionary of 1000 entries of 4..28 bytes: offsets + gathered bytes."""
+    """10^8 indices into a dictionary of 1000 entries of 4..28 bytes: offsets + gathered bytes.
+    (DICT_ENTRIES / DICT_MAX_LEN in the environment: another dictionary, e.g. one too large for LDS.)"""
+    import os
     n = 100_000_000
+    entries = int(os.environ.get("DICT_ENTRIES", "1000"))
+    max_len = int(os.environ.get("DICT_MAX_LEN", "28"))
     g = torch.Generator(device="cuda")
     g.manual_seed(1)
-    lens = torch.randint(4, 29, (1000,), device="cuda", generator=g)
-    doff = torch.zeros(1001, dtype=torch.int64, device="cuda")
+    lens = torch.randint(4, max_len + 1, (entries,), device="cuda", generator=g)
+    doff = torch.zeros(entries + 1, dtype=torch.int64, device="cuda")
     doff[1:] = torch.cumsum(lens, 0)
     dbytes = torch.randint(97, 123, (int(doff[-1]),), dtype=torch.uint8, device="cuda", generator=g)
-    idx = torch.randint(0, 1000, (n,), dtype=torch.int64, device="cuda", generator=g)
+    idx = torch.randint(0, entries, (n,), dtype=torch.int64, device="cuda", generator=g)
     want_off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
     want_off[1:] = torch.cumsum(lens[idx], 0)
     total = int(want_off[-1])
@@ -81,9 +85,15 @@ def dictionary(ctx):
     out = torch.empty(total, dtype=torch.uint8, device="cuda")
     lib = N.lib()
     dt = timed(ctx, lambda: check(lib.orcd_string_dictionary_decode(
-        ctx.handle, doff.data_ptr(), dbytes.data_ptr(), 1000, idx.data_ptr(), n, offsets.data_ptr(),
+        ctx.handle, doff.data_ptr(), dbytes.data_ptr(), entries, idx.data_ptr(), n, offsets.data_ptr(),
         out.data_ptr(), total, N.IN_DEVICE | N.OUT_DEVICE), ctx.handle))
     assert torch.equal(offsets, want_off)
+    for k in (0, 1, 12345, n // 2, n - 1):  # a few values, byte for byte
+        a, b = int(want_off[k]), int(want_off[k + 1])
+        e = int(idx[k])
+        assert torch.equal(out[a:b], dbytes[int(doff[e]):int(doff[e + 1])]), k
+    probe = torch.arange(0, n, 4099, device="cuda")  # the first byte of every 4099th value
+    assert torch.equal(out[want_off[probe]], dbytes[doff[idx[probe]]])
     print("dictionary: %d values, %d bytes out, %.3f ms, %.0f GB/s of bytes + offsets" %
           (n, total, dt * 1e3, (total + 8 * n) / dt / 1e9), flush=True)
 

@@ -1942,13 +1942,15 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
 // n_chunks + 1 entries, the last one the total, which *total receives too.  num_values > 0.
 static int dictionary_sums(orcd_ctx *c, const int64_t *d_dict_off, size_t dict_size, size_t dict_total,
                            const int64_t *d_idx, size_t num_values, const uint64_t **chunk_prefix,
-                           uint64_t *total) {
+                           uint64_t *total, uint32_t *max_len) {
     const uint64_t n_chunks = ((uint64_t)num_values + 63) / 64;
     void *flag, *sums, *chunk_sums;
     ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
     ORCD_TRY(ensure(c, SLOT_TMP, (n_chunks + 1) * sizeof(uint64_t), &chunk_sums));
     ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(n_chunks) * sizeof(uint64_t), &sums));
-    HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(flag, 0, 2 * sizeof(uint32_t), c->stream));
+    // (the second word: the longest entry, which picks the gather's kernel)
+    HIP_TRY(c, launch_dictionary_max_len(c->stream, d_dict_off, dict_size, (uint32_t *)flag + 1));
     HIP_TRY(c, launch_dictionary_chunk_sums(c->stream, d_dict_off, dict_size, dict_total, d_idx, num_values,
                                             (uint64_t *)chunk_sums, (uint32_t *)flag));
     // (a chunk holds at most 64 * dict_total bytes; the limit only has to stay below 2^52)
@@ -1956,9 +1958,10 @@ static int dictionary_sums(orcd_ctx *c, const int64_t *d_dict_off, size_t dict_s
     HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)chunk_sums, n_chunks, (uint64_t *)sums,
                                          chunk_limit, (uint32_t *)flag));
     HIP_TRY(c, hipMemcpyAsync(c->h_scalars, (uint64_t *)chunk_sums + n_chunks, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint32_t bad = *(uint32_t *)(c->h_scalars + 1);
+    *max_len = ((uint32_t *)(c->h_scalars + 1))[1];
     if (bad & 2u) return ORCD_INVALID_ARGUMENT;  // dict_offsets do not describe dict_bytes
     if (bad & 1u) return dict_total >= (1ull << 46) ? ORCD_INVALID_ARGUMENT : ORCD_OUT_OF_SPEC;
     *total = c->h_scalars[0];
@@ -2003,8 +2006,9 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
     }
     uint64_t total = 0;
     const uint64_t *chunk_prefix = nullptr;
+    uint32_t max_len = 0;
     ORCD_TRY(dictionary_sums(c, (const int64_t *)d_dict_off, dict_size, dict_total, (const int64_t *)d_idx,
-                             num_values, &chunk_prefix, &total));
+                             num_values, &chunk_prefix, &total, &max_len));
     uint8_t *d_bytes = bytes_out;
     if (bytes_out) {
         if (total > bytes_capacity) return ORCD_INVALID_ARGUMENT;
@@ -2016,7 +2020,7 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
     }
     HIP_TRY(c, launch_dictionary_gather(c->stream, (const int64_t *)d_dict_off, (const uint8_t *)d_dict_bytes,
                                         dict_size, dict_total, (const int64_t *)d_idx, num_values,
-                                        chunk_prefix, d_offsets, d_bytes));
+                                        chunk_prefix, d_offsets, d_bytes, max_len));
     mark(c, 3);
     if (!out_dev) {
         ORCD_TRY(result_to_host(c, offsets_out, d_offsets, (num_values + 1) * sizeof(int64_t)));
@@ -2535,12 +2539,13 @@ int column_values(orcd_ctx *c, const ColumnStreams &cs, int type_kind, unsigned 
                 const uint64_t dict_total = c->h_scalars[0];
                 uint64_t total = 0;
                 const uint64_t *chunk_prefix = nullptr;
+                uint32_t max_len = 0;
                 ORCD_TRY(dictionary_sums(c, (const int64_t *)p.tmp, dict_size, dict_total, (const int64_t *)d_idx,
-                                         n_values, &chunk_prefix, &total));
+                                         n_values, &chunk_prefix, &total, &max_len));
                 ORCD_TRY(dev_alloc(c, total, &p.bytes));
                 HIP_TRY(c, launch_dictionary_gather(c->stream, (const int64_t *)p.tmp, (const uint8_t *)p.tmp2,
                                                     dict_size, dict_total, (const int64_t *)d_idx, n_values,
-                                                    chunk_prefix, (int64_t *)p.offsets, (uint8_t *)p.bytes));
+                                                    chunk_prefix, (int64_t *)p.offsets, (uint8_t *)p.bytes, max_len));
             }
         } else {
             return ORCD_UNSUPPORTED;  // an encoding the format does not define

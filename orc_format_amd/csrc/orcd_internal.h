@@ -304,13 +304,14 @@ hipError_t launch_string_bytes(hipStream_t st, const uint8_t *src, uint8_t *dst,
 // of *error_flag an index out of range, bit 1 offsets that do not describe the dictionary), and,
 // given the exclusive prefix sums of those (n_chunks + 1 entries, the last one the total), the
 // values' offsets (n + 1) and -- bytes_out not null -- their bytes.
+hipError_t launch_dictionary_max_len(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size, uint32_t *max_len);
 hipError_t launch_dictionary_chunk_sums(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
                                         uint64_t dict_total, const int64_t *indices, uint64_t n,
                                         uint64_t *chunk_sums, uint32_t *error_flag);
 hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
                                     const uint8_t *dict_bytes, uint64_t dict_size, uint64_t dict_total,
                                     const int64_t *indices, uint64_t n, const uint64_t *chunk_prefix,
-                                    int64_t *offsets_out, uint8_t *bytes_out);
+                                    int64_t *offsets_out, uint8_t *bytes_out, uint32_t max_len);
 
 // Null scatter: per-tile counts of valid rows, then (after an exclusive scan of the counts)
 // out[r] = dense[number of valid rows before r] for valid rows, zero for null rows -- or the same

@@ -371,6 +371,23 @@ hipError_t launch_string_bytes(hipStream_t st, const uint8_t *src, uint8_t *dst,
 // dictionary gather (tests/it/deserialize.rs:142-185)
 // ---------------------------------------------------------------------------------------------
 
+// Inclusive prefix sums over the 64 lanes with DPP row shifts and row broadcasts: shifts by 1, 2,
+// 4, 8 scan each row of 16 lanes, then lane 15 of rows 0 and 2 is added to rows 1 and 3, then lane
+// 31 to rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_dpp(uint32_t v) {
+    v += dpp_or_zero<0x111, 0xF>(v);
+    v += dpp_or_zero<0x112, 0xF>(v);
+    v += dpp_or_zero<0x114, 0xF>(v);
+    v += dpp_or_zero<0x118, 0xF>(v);
+    v += dpp_or_zero<0x142, 0xA>(v);
+    v += dpp_or_zero<0x143, 0xC>(v);
+    return v;
+}
+
 // chunk_sums[c] = bytes that values [64c, 64c + 64) hold together (saturating); the indices and
 // the dictionary offsets are checked on the way.  The lengths themselves are never stored: the
 // gather recomputes them and places every value by a wave scan on top of the scanned chunk sums.
@@ -418,20 +435,40 @@ __global__ __launch_bounds__(256) void dictionary_chunk_sums_lds_kernel(
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t n_chunks = (n + 63) / 64;
-    for (uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks;
-         chunk += (uint64_t)gridDim.x * 4) {
-        const uint64_t i = chunk * 64 + lane;
-        uint64_t l = 0;
-        if (i < n) {
-            const uint64_t idx = (uint64_t)indices[i];
-            if (idx >= dict_size) atomicOr(error_flag, 1u);  // deserialize.rs:162 -> OutOfSpec
-            else l = l_len[idx];
+    // a wavefront takes four chunks at a time: four loads of indices in flight, four sums by DPP
+    // (64 lengths below 2^32 each: the sum is done in two halves that cannot wrap)
+    const uint64_t n_quads = (n_chunks + 3) / 4;
+    // (... and the next four are asked for before these are looked up)
+    auto load4 = [&](uint64_t quad, uint64_t (&idx)[4]) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint64_t i = (quad * 4 + j) * 64 + lane;
+            idx[j] = (quad < n_quads && i < n) ? (uint64_t)indices[i] : 0;
         }
-        for (int d = 32; d >= 1; d >>= 1) {  // 64 lengths below 2^32 each: the sum cannot wrap
-            const uint32_t lo = __shfl_xor((uint32_t)l, d), hi = __shfl_xor((uint32_t)(l >> 32), d);
-            l += ((uint64_t)hi << 32) | lo;
+    };
+    const uint64_t quad_step = (uint64_t)gridDim.x * 4;
+    uint64_t quad = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint64_t idx_next[4];
+    load4(quad, idx_next);
+    for (; quad < n_quads; quad += quad_step) {
+        uint64_t idx[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) idx[j] = idx_next[j];
+        load4(quad + quad_step, idx_next);
+        bool bad = false;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint64_t chunk = quad * 4 + j;
+            const uint64_t i = chunk * 64 + lane;
+            uint32_t l = 0;
+            if (i < n) {
+                if (idx[j] >= dict_size) bad = true;  // deserialize.rs:162 -> OutOfSpec
+                else l = l_len[idx[j]];
+            }
+            const uint32_t lo = wave_inclusive_dpp(l & 0xFFFFu), hi = wave_inclusive_dpp(l >> 16);
+            if (lane == 63 && chunk < n_chunks) chunk_sums[chunk] = ((uint64_t)hi << 16) + lo;
         }
-        if (lane == 0) chunk_sums[chunk] = l;
+        if (bad) atomicOr(error_flag, 1u);
     }
 }
 
@@ -467,48 +504,83 @@ __device__ __forceinline__ void copy_value(uint8_t *dst, const uint8_t *src, uin
     }
 }
 
-// A wavefront takes 64 consecutive values: their bytes form one stretch of the output.  Each lane
-// copies its value out of the dictionary into an LDS image of that stretch (laid out at the
-// stretch's own 16-byte phase), and the wavefront then writes the image with 16-byte stores, 1 KiB
-// per instruction; the first and last 16 bytes, which neighbouring wavefronts share, go byte by
-// byte.  A stretch longer than the image is copied value by value straight to the output.
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// A wavefront takes 64 consecutive values: their bytes form one stretch of the output.  The
+// stretch is put together in LDS, laid out at its own 16-byte phase, and then written with 16-byte
+// stores, 1 KiB per instruction; the first and last 16 bytes, which neighbouring wavefronts share,
+// go byte by byte.  Into the image each lane moves its value a destination dword at a time: the
+// dword is cut out of the two aligned dictionary dwords it straddles (v_alignbyte), the bytes
+// outside the value are masked off, and what is left is OR-ed into the zeroed image -- so two
+// values that share a dword need not know of each other, and no lane ever moves a single byte or
+// waits for a load before it may store.  The wavefront makes as many such steps as its longest
+// value has dwords.  A stretch longer than the image takes it several times, a value joining
+// in each pass with the dwords that fall into it.
+// SHORT: no entry is longer than DG_SHORT_LEN bytes, so the stretch fits the image and the steps
+// are unrolled; the two cases are two kernels because together they need more registers than eight
+// wavefronts per SIMD leave, and the spills land in the common case's loop.
 // LDS_DICT: the dictionary itself (32-bit offsets + bytes) is small enough to live in LDS; every
 // workgroup copies it there once and then takes chunks of values in turn, so that the per-value
 // reads -- two offsets and a few dwords at a random place -- never leave the compute unit.
-constexpr uint32_t DG_IMAGE = 4096;        // bytes of output 64 values may hold to take the LDS way
+constexpr uint32_t DG_IMAGE = 2048;        // bytes of a stretch the LDS image takes at a time
+constexpr uint32_t DG_IMAGE_LONG = 4096;   // ... in the kernel for dictionaries with long entries
 constexpr uint32_t DG_DICT_LDS = 48 << 10;  // dictionary offsets + bytes that may live in LDS
+constexpr uint32_t DG_SHORT_LEN = 32;        // entries up to this long: DG_IMAGE / 64
+constexpr uint32_t DG_THREADS = 512;
+constexpr uint32_t DG_WAVES = DG_THREADS / 64;
 
-template <bool LDS_DICT>
-__global__ __launch_bounds__(256) void dictionary_gather_kernel(
+template <bool LDS_DICT, bool SHORT>
+__global__ __launch_bounds__(DG_THREADS, SHORT ? 8 : 6) void dictionary_gather_kernel(
     const int64_t *__restrict__ dict_offsets, const uint8_t *__restrict__ dict_bytes,
     uint64_t dict_total, uint64_t dict_size, const int64_t *__restrict__ indices, uint64_t n,
     const uint64_t *__restrict__ chunk_prefix, int64_t *__restrict__ offsets_out,
     uint8_t *__restrict__ bytes_out) {
-    __shared__ __attribute__((aligned(16))) uint8_t image_all[4][DG_IMAGE + 32];
+    constexpr uint32_t IMG = SHORT ? DG_IMAGE : DG_IMAGE_LONG;
+    __shared__ __attribute__((aligned(16))) uint8_t image_all[DG_WAVES][IMG + 32];
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
     uint32_t *l_off = (uint32_t *)dyn;                                  // [dict_size + 1]
     uint8_t *l_bytes = dyn + (((size_t)dict_size + 1) * 4 + 15) / 16 * 16;  // dictionary bytes at their own 4-byte phase
     const uint32_t phase = (uint32_t)((uintptr_t)dict_bytes & 3);
+    // the aligned dwords that each hold a dictionary byte: [0, n_words) of dict_bytes - phase
+    const uint32_t *g_words = (const uint32_t *)(dict_bytes - phase);
+    const uint64_t n_words = (dict_total + phase + 3) / 4;
     if (LDS_DICT) {
         for (uint64_t k = threadIdx.x; k <= dict_size; k += blockDim.x) l_off[k] = (uint32_t)dict_offsets[k];
-        const uint32_t *src = (const uint32_t *)(dict_bytes - phase);  // aligned dwords that each hold a dictionary byte
-        const uint64_t n_words = (dict_total + phase + 3) / 4;
-        for (uint64_t k = threadIdx.x; k < n_words; k += blockDim.x) ((uint32_t *)l_bytes)[k] = src[k];
+        for (uint64_t k = threadIdx.x; k < n_words; k += blockDim.x) ((uint32_t *)l_bytes)[k] = g_words[k];
         __syncthreads();
     }
-    uint8_t *image = image_all[threadIdx.x >> 6];
-    const uint32_t lane = threadIdx.x & 63;
-    const uintptr_t last_word = LDS_DICT ? ~(uintptr_t)0  // (the LDS copy is padded: a dword past the end may be read)
-                                         : ((uintptr_t)(dict_bytes + dict_total - 1)) & ~(uintptr_t)3;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t *image = (uint32_t *)image_all[wave];
+    const uintptr_t last_word = ((uintptr_t)(dict_bytes + dict_total - 1)) & ~(uintptr_t)3;
     const uint64_t n_chunks = (n + 63) / 64;
-    for (uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks;
-         chunk += (uint64_t)gridDim.x * 4) {
+    const uint64_t chunk_step = (uint64_t)gridDim.x * DG_WAVES;
+    // the next chunk's index and bounds are asked for a chunk ahead: the round trip to memory
+    // would otherwise stand in front of everything a wavefront does for a chunk
+    uint64_t chunk = (uint64_t)blockIdx.x * DG_WAVES + wave;
+    uint64_t idx_next = 0, o0_next = 0, o1_next = 0;
+    if (chunk < n_chunks) {
+        if (chunk * 64 + lane < n) idx_next = (uint64_t)indices[chunk * 64 + lane];
+        o0_next = chunk_prefix[chunk];
+        o1_next = chunk_prefix[chunk + 1];
+    }
+    for (; chunk < n_chunks; chunk += chunk_step) {
         const uint64_t i0 = chunk * 64;
         const uint64_t i = i0 + lane;
         const bool live = i < n;
+        const uint64_t idx = idx_next;
+        const uint64_t o0 = o0_next, o1 = o1_next;  // wave-uniform: where the chunk's bytes start and end
+        if (chunk + chunk_step < n_chunks) {
+            const uint64_t nc = chunk + chunk_step;
+            idx_next = nc * 64 + lane < n ? (uint64_t)indices[nc * 64 + lane] : 0;
+            o0_next = chunk_prefix[nc];
+            o1_next = chunk_prefix[nc + 1];
+        }
         uint64_t src0 = 0, len = 0;
         if (live) {
-            const uint64_t idx = (uint64_t)indices[i];
             if (idx < dict_size) {  // checked before: always
                 if (LDS_DICT) {
                     src0 = l_off[idx];
@@ -520,13 +592,15 @@ __global__ __launch_bounds__(256) void dictionary_gather_kernel(
             }
             if (src0 > dict_total || len > dict_total - src0) len = 0;  // checked before: never taken
         }
-        const uint8_t *src = LDS_DICT ? l_bytes + phase + src0 : dict_bytes + src0;
-        // where the chunk's bytes start and end, and this value's place among them
-        const uint64_t o0 = chunk_prefix[chunk], o1 = chunk_prefix[chunk + 1];  // wave-uniform
+        // this value's place among the chunk's bytes
         uint64_t incl = len;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t lo = __shfl_up((uint32_t)incl, d), hi = __shfl_up((uint32_t)(incl >> 32), d);
-            if (lane >= (uint32_t)d) incl += ((uint64_t)hi << 32) | lo;
+        if (dict_total < (1u << 25)) {  // 64 lengths add up in 32 bits
+            incl = wave_inclusive_dpp((uint32_t)len);
+        } else {
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t lo = __shfl_up((uint32_t)incl, d), hi = __shfl_up((uint32_t)(incl >> 32), d);
+                if (lane >= (uint32_t)d) incl += ((uint64_t)hi << 32) | lo;
+            }
         }
         const uint64_t off = o0 + incl - len;
         if (live) {
@@ -535,30 +609,126 @@ __global__ __launch_bounds__(256) void dictionary_gather_kernel(
         }
         if (!bytes_out) continue;  // offsets only
         const uint64_t total = o1 - o0;
-        if (o1 < o0 || total > DG_IMAGE) {
-            if (len) copy_value(bytes_out + off, src, len, last_word);
+        // (the scanned sums and the wave scan agree unless the sums were not of these values)
+        // (... and the image's addressing is 32-bit: 2 GiB and more go the slow way)
+        if (o1 < o0 || total > 0x7FFFFF00ull || readlane_u64(incl, 63) != total || dict_total > 0x7FFFFFF0ull) {
+            if (len && o1 >= o0 && off + len <= o1) copy_value(bytes_out + off, dict_bytes + src0, len, last_word);
             continue;
         }
+        if (total == 0) continue;
         uint8_t *stretch = bytes_out + o0;
         const uint32_t lead = (uint32_t)((uintptr_t)stretch & 15);
-        if (len && off >= o0 && off - o0 + len <= total)
-            copy_value(image + lead + (uint32_t)(off - o0), src, len, last_word);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // 16-byte pieces of the image [lead, lead + total): piece c holds image bytes [16c, 16c + 16)
-        const uint32_t end = lead + (uint32_t)total;
+        const uint32_t end = lead + (uint32_t)total;  // the stretch is bytes [lead, end) of the aligned pieces
         uint8_t *aligned = stretch - lead;
-        for (uint32_t c = lane; c * 16 < end; c += 64) {
-            const uint32_t b0 = c * 16, b1 = b0 + 16;
-            if (b0 >= lead && b1 <= end) {
-                *(uint4 *)(aligned + b0) = *(const uint4 *)(image + b0);
-            } else {
-                for (uint32_t b = b0 < lead ? lead : b0; b < (b1 < end ? b1 : end); b++) aligned[b] = image[b];
+        const uint8_t *image8 = (const uint8_t *)image;
+        const uint32_t l = (uint32_t)len;
+        const uint32_t dst = lead + (uint32_t)(incl - len);      // byte of the value's first, counted like `end`
+        const uint32_t dsk = dst & 3;                            // ... and its place in its dword
+        // destination dword k of the value holds its bytes 4k - dsk .. 4k - dsk + 3, which are the
+        // dictionary's bytes from `from` + 4k on (counted from the first aligned dword; up to 3
+        // below zero for a value at the very start: masked off, never loaded)
+        const int32_t from = (int32_t)((uint32_t)src0 + phase) - (int32_t)dsk;
+        const uint32_t sh = (uint32_t)from & 3;
+        const int32_t q0 = from >> 2;
+        const uint32_t n_dw = l ? (dsk + l + 3) >> 2 : 0;
+        const uint32_t d0 = dst >> 2;  // the value's dwords are d0 .. d0 + n_dw - 1
+        auto word = [&](int32_t q) -> uint32_t {
+            if (LDS_DICT) return ((const uint32_t *)l_bytes)[q];  // (padded on both sides)
+            return (q >= 0 && (uint64_t)q < n_words) ? g_words[q] : 0u;
+        };
+        auto put = [&](uint32_t k, uint32_t w_lo, uint32_t w_hi, uint32_t wd0) {
+            const uint32_t v = __builtin_amdgcn_alignbyte(w_hi, w_lo, sh);
+            const int32_t first = (int32_t)(4 * k) - (int32_t)dsk;  // value byte under the dword's byte 0
+            uint32_t m = 0xFFFFFFFFu;
+            if (first < 0) m <<= 8 * (uint32_t)(-first);            // (k = 0 only: 1..3 bytes of the neighbour before)
+            const int32_t over = first + 4 - (int32_t)l;            // at most 3, as k < n_dw
+            if (over > 0) m &= 0xFFFFFFFFu >> (8 * (uint32_t)over);
+            // (a dword that is all this value's needs no OR: most of a long value's are)
+            if (!SHORT && m == 0xFFFFFFFFu) image[d0 + k - wd0] = v;
+            else atomicOr(&image[d0 + k - wd0], v & m);
+        };
+        // 16-byte pieces of the image, which holds bytes [wb, we): piece c is bytes [wb + 16c, wb + 16c + 16)
+        auto write_out = [&](uint32_t wb, uint32_t we) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t c = lane; c * 16 < we - wb; c += 64) {
+                const uint32_t b0 = wb + c * 16, b1 = b0 + 16;
+                if (b0 >= lead && b1 <= end) {
+                    *(uint4 *)(aligned + b0) = *(const uint4 *)(image8 + c * 16);
+                } else {
+                    for (uint32_t b = b0 < lead ? lead : b0; b < (b1 < end ? b1 : end); b++) aligned[b] = image8[b - wb];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the image's next writes come after these reads
+        };
+        auto clear = [&](uint32_t bytes) {
+            for (uint32_t c = lane; c * 16 < bytes; c += 64) ((uint4 *)image)[c] = make_uint4(0, 0, 0, 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        if constexpr (SHORT) {
+            // no entry of the dictionary is longer than DG_SHORT_LEN bytes (the launcher has looked):
+            // the stretch fits the image (64 values of 16 bytes fill half of it), a value has at
+            // most DG_UNROLLED dwords, and every load goes out before the first store waits for one
+            constexpr uint32_t DG_UNROLLED = (DG_SHORT_LEN + 3 + 3) / 4;
+            if (end > DG_IMAGE + 15 || __any(n_dw > DG_UNROLLED)) continue;  // (never)
+            clear(end);
+            uint32_t w[DG_UNROLLED + 1];
+#pragma unroll
+            for (uint32_t k = 0; k <= DG_UNROLLED; k++) w[k] = k <= n_dw && n_dw ? word(q0 + (int32_t)k) : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < DG_UNROLLED; k++)
+                if (k < n_dw) put(k, w[k], w[k + 1], 0);
+            write_out(0, end);
+        } else {
+            // The image takes the stretch IMG bytes at a time, a value joining in each pass
+            // with the dwords that fall into it, four per step.
+            for (uint32_t wb = 0; wb < end; wb += IMG) {
+                const uint32_t we = end - wb < IMG ? end : wb + IMG;  // this pass: bytes [wb, we)
+                clear(we - wb);
+                const uint32_t wd0 = wb >> 2, wd1 = (wb + IMG) >> 2;
+                const uint32_t k_lo = wd0 > d0 ? wd0 - d0 : 0;
+                const uint32_t k_hi = d0 + n_dw > wd1 ? (wd1 > d0 ? wd1 - d0 : 0) : n_dw;
+                uint32_t w0 = k_lo < k_hi ? word(q0 + (int32_t)k_lo) : 0u;
+                for (uint32_t k = k_lo; __any(k < k_hi); k += 4) {
+                    uint32_t w[5];
+                    w[0] = w0;
+#pragma unroll
+                    for (uint32_t j = 1; j <= 4; j++) w[j] = k + j <= k_hi ? word(q0 + (int32_t)(k + j)) : 0u;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++)
+                        if (k + j < k_hi) put(k + j, w[j], w[j + 1], wd0);
+                    w0 = w[4];
+                }
+                write_out(wb, we);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // the next chunk's image writes come after these reads
     }
+}
+
+// *max_len = max(*max_len, length of the longest entry); entries whose offsets descend count as 0
+// (the sums kernels report them).
+__global__ __launch_bounds__(256) void dictionary_max_len_kernel(const int64_t *__restrict__ dict_offsets,
+                                                                 uint64_t dict_size, uint32_t *__restrict__ max_len) {
+    uint64_t m = 0;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < dict_size; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = (uint64_t)dict_offsets[k], e = (uint64_t)dict_offsets[k + 1];
+        if (e > b && e - b > m) m = e - b;
+    }
+    uint32_t v = m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)m;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(v, d);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(max_len, v);
+}
+
+hipError_t launch_dictionary_max_len(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size, uint32_t *max_len) {
+    if (dict_size == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((dict_size + 255) / 256, 64);
+    dictionary_max_len_kernel<<<blocks, 256, 0, st>>>(dict_offsets, dict_size, max_len);
+    return hipGetLastError();
 }
 
 hipError_t launch_dictionary_chunk_sums(hipStream_t st, const int64_t *dict_offsets, uint64_t dict_size,
@@ -580,18 +750,21 @@ hipError_t launch_dictionary_chunk_sums(hipStream_t st, const int64_t *dict_offs
 hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
                                     const uint8_t *dict_bytes, uint64_t dict_size, uint64_t dict_total,
                                     const int64_t *indices, uint64_t n, const uint64_t *chunk_prefix,
-                                    int64_t *offsets_out, uint8_t *bytes_out) {
+                                    int64_t *offsets_out, uint8_t *bytes_out, uint32_t max_len) {
     if (n == 0) return hipSuccess;
     const uint64_t chunks = (n + 63) / 64;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((chunks + 3) / 4, 256 * 8);  // workgroups take chunks in turn
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((chunks + DG_WAVES - 1) / DG_WAVES, 256 * 4);  // workgroups take chunks in turn
     const uint64_t lds = ((dict_size + 1) * 4 + 15) / 16 * 16 + dict_total + 16;
-    if (lds <= DG_DICT_LDS && dict_total < 0xFFFFFFFFull) {
-        dictionary_gather_kernel<true><<<blocks, 256, (size_t)lds, st>>>(
-            dict_offsets, dict_bytes, dict_total, dict_size, indices, n, chunk_prefix, offsets_out, bytes_out);
-    } else {
-        dictionary_gather_kernel<false><<<blocks, 256, 0, st>>>(
-            dict_offsets, dict_bytes, dict_total, dict_size, indices, n, chunk_prefix, offsets_out, bytes_out);
-    }
+    const bool in_lds = lds <= DG_DICT_LDS && dict_total < 0xFFFFFFFFull;
+    const bool is_short = max_len <= DG_SHORT_LEN;  // max_len: of the dictionary's entries (dictionary_max_len_kernel)
+#define ORCD_DG_LAUNCH(L, S)                                                                       \
+    dictionary_gather_kernel<L, S><<<blocks, DG_THREADS, (L) ? (size_t)lds : 0, st>>>(               \
+        dict_offsets, dict_bytes, dict_total, dict_size, indices, n, chunk_prefix, offsets_out, bytes_out)
+    if (in_lds && is_short) ORCD_DG_LAUNCH(true, true);
+    else if (in_lds) ORCD_DG_LAUNCH(true, false);
+    else if (is_short) ORCD_DG_LAUNCH(false, true);
+    else ORCD_DG_LAUNCH(false, false);
+#undef ORCD_DG_LAUNCH
     return hipGetLastError();
 }
 

@@ -429,17 +429,34 @@ def test_strings_random(gpu, oracle):
     assert rc == 0 and (o_gpu == o_ref).all() and b_gpu.tobytes() == b_ref.tobytes()
 
 
-@pytest.mark.parametrize("shape", ["small_dict", "large_dict", "long_values", "empty_values"])
+DICT_SHAPES = ["small_dict", "large_dict", "long_values", "empty_values", "large_short_dict",
+               "longest_short", "shortest_long", "one_long_entry"]
+
+
+@pytest.mark.parametrize("shape", DICT_SHAPES)
 def test_dictionary_gather_shapes(gpu, oracle, shape):
-    """The gather's ways through: dictionary held in LDS or read from memory, 64 values whose
-    bytes fit the LDS image or not, empty entries, every alignment of the output stretch."""
-    rng = np.random.default_rng(["small_dict", "large_dict", "long_values", "empty_values"].index(shape) + 40)
+    """The gather's ways through: dictionary held in LDS or read from memory, entries all short
+    (one kernel: 64 values fit the LDS image) or not (another: the image is filled several times),
+    the longest entry on either side of that line, empty entries, every alignment of the output
+    stretch."""
+    rng = np.random.default_rng(DICT_SHAPES.index(shape) + 40)
     if shape == "small_dict":
         lens = rng.integers(1, 30, size=300)
     elif shape == "large_dict":
         lens = rng.integers(1, 40, size=6000)       # 120 KB of bytes: not in LDS
     elif shape == "long_values":
         lens = rng.integers(0, 400, size=50)         # 64 values often exceed the image
+    elif shape == "large_short_dict":
+        lens = rng.integers(0, 33, size=8000)        # not in LDS, no entry over 32 bytes
+    elif shape == "longest_short":
+        lens = rng.integers(28, 33, size=100)        # 64 values fill the image to the last byte
+        lens[7] = 32
+    elif shape == "shortest_long":
+        lens = rng.integers(28, 33, size=100)
+        lens[7] = 33
+    elif shape == "one_long_entry":
+        lens = rng.integers(1, 9, size=400)
+        lens[123] = 9000                             # one value spans several fillings of the image
     else:
         lens = rng.integers(0, 3, size=200)          # many empty entries
     doff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
