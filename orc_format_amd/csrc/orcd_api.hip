@@ -1939,35 +1939,53 @@ int orcd_string_direct_decode(orcd_ctx *c, const uint8_t *length_stream, size_t 
 
 // First phase of a dictionary decode, all on the device: the bytes every chunk of 64 values
 // holds, scanned.  *chunk_prefix (in a buffer of the context, valid until its next call) gets
-// n_chunks + 1 entries, the last one the total, which *total receives too.  num_values > 0.
-static int dictionary_sums(orcd_ctx *c, const int64_t *d_dict_off, size_t dict_size, size_t dict_total,
-                           const int64_t *d_idx, size_t num_values, const uint64_t **chunk_prefix,
-                           uint64_t *total, uint32_t *max_len) {
+// n_chunks + 1 entries, the last one the total.  num_values > 0.  Only launches: what the phase
+// found is for dictionary_sums_verdict to fetch.
+// max_len: null, or receives the longest entry (which picks the gather's kernel) with the verdict.
+static int dictionary_sums_launch(orcd_ctx *c, const int64_t *d_dict_off, size_t dict_size, size_t dict_total,
+                                  const int64_t *d_idx, size_t num_values, const uint64_t **chunk_prefix,
+                                  bool want_max_len) {
     const uint64_t n_chunks = ((uint64_t)num_values + 63) / 64;
     void *flag, *sums, *chunk_sums;
     ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
     ORCD_TRY(ensure(c, SLOT_TMP, (n_chunks + 1) * sizeof(uint64_t), &chunk_sums));
     ORCD_TRY(ensure(c, SLOT_SCAN_SUMS, scan_block_sums_len(n_chunks) * sizeof(uint64_t), &sums));
     HIP_TRY(c, hipMemsetAsync(flag, 0, 2 * sizeof(uint32_t), c->stream));
-    // (the second word: the longest entry, which picks the gather's kernel)
-    HIP_TRY(c, launch_dictionary_max_len(c->stream, d_dict_off, dict_size, (uint32_t *)flag + 1));
+    if (want_max_len)  // (the second word)
+        HIP_TRY(c, launch_dictionary_max_len(c->stream, d_dict_off, dict_size, (uint32_t *)flag + 1));
     HIP_TRY(c, launch_dictionary_chunk_sums(c->stream, d_dict_off, dict_size, dict_total, d_idx, num_values,
                                             (uint64_t *)chunk_sums, (uint32_t *)flag));
     // (a chunk holds at most 64 * dict_total bytes; the limit only has to stay below 2^52)
     const uint64_t chunk_limit = std::min<uint64_t>((uint64_t)dict_total * 64, (1ull << 52) - 1);
     HIP_TRY(c, launch_exclusive_scan_u64(c->stream, (uint64_t *)chunk_sums, n_chunks, (uint64_t *)sums,
                                          chunk_limit, (uint32_t *)flag));
-    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, (uint64_t *)chunk_sums + n_chunks, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    *chunk_prefix = (const uint64_t *)chunk_sums;
+    return ORCD_OK;
+}
+
+// What dictionary_sums_launch found (waits for the stream): the column's bytes in *total, or the error.
+static int dictionary_sums_verdict(orcd_ctx *c, size_t dict_total, size_t num_values, const uint64_t *chunk_prefix,
+                                   uint64_t *total, uint32_t *max_len) {
+    const uint64_t n_chunks = ((uint64_t)num_values + 63) / 64;
+    void *flag;
+    ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
+    HIP_TRY(c, hipMemcpyAsync(c->h_scalars, chunk_prefix + n_chunks, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint32_t bad = *(uint32_t *)(c->h_scalars + 1);
-    *max_len = ((uint32_t *)(c->h_scalars + 1))[1];
+    if (max_len) *max_len = ((uint32_t *)(c->h_scalars + 1))[1];
     if (bad & 2u) return ORCD_INVALID_ARGUMENT;  // dict_offsets do not describe dict_bytes
     if (bad & 1u) return dict_total >= (1ull << 46) ? ORCD_INVALID_ARGUMENT : ORCD_OUT_OF_SPEC;
     *total = c->h_scalars[0];
     if (*total == ~0ull) return ORCD_INVALID_ARGUMENT;  // the column would exceed 2^64 bytes
-    *chunk_prefix = (const uint64_t *)chunk_sums;
     return ORCD_OK;
+}
+
+static int dictionary_sums(orcd_ctx *c, const int64_t *d_dict_off, size_t dict_size, size_t dict_total,
+                           const int64_t *d_idx, size_t num_values, const uint64_t **chunk_prefix,
+                           uint64_t *total, uint32_t *max_len) {
+    ORCD_TRY(dictionary_sums_launch(c, d_dict_off, dict_size, dict_total, d_idx, num_values, chunk_prefix, true));
+    return dictionary_sums_verdict(c, dict_total, num_values, *chunk_prefix, total, max_len);
 }
 
 int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
@@ -1982,13 +2000,25 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
     size_t dict_total = 0;
     const void *d_dict_off, *d_dict_bytes, *d_idx;
     ORCD_TRY(stage_in(c, SLOT_IN_C, dict_offsets, (dict_size + 1) * sizeof(int64_t), in_dev, &d_dict_off));
+    // the dictionary's size, and its longest entry (which picks the gather's kernel)
+    uint32_t max_len = 0;
     if (in_dev) {
+        void *flag;
+        ORCD_TRY(ensure(c, SLOT_FLAGS, 64, &flag));
+        HIP_TRY(c, hipMemsetAsync(flag, 0, 2 * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, launch_dictionary_max_len(c->stream, (const int64_t *)d_dict_off, dict_size, (uint32_t *)flag + 1));
         HIP_TRY(c, hipMemcpyAsync(c->h_scalars, dict_offsets + dict_size, sizeof(int64_t),
                                   hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_scalars + 1, flag, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         dict_total = (size_t)c->h_scalars[0];
+        max_len = ((uint32_t *)(c->h_scalars + 1))[1];
     } else {
         dict_total = (size_t)dict_offsets[dict_size];
+        for (size_t k = 0; k < dict_size; k++) {
+            const uint64_t b = (uint64_t)dict_offsets[k], e = (uint64_t)dict_offsets[k + 1];
+            if (e > b) max_len = (uint32_t)std::max<uint64_t>(max_len, std::min<uint64_t>(e - b, 0xFFFFFFFFull));
+        }
     }
     if ((dict_total && !dict_bytes) || dict_total >= (1ull << 52)) return ORCD_INVALID_ARGUMENT;
     ORCD_TRY(stage_in(c, SLOT_IN_B, dict_bytes, dict_total, in_dev, &d_dict_bytes));
@@ -2006,17 +2036,26 @@ int orcd_string_dictionary_decode(orcd_ctx *c, const int64_t *dict_offsets,
     }
     uint64_t total = 0;
     const uint64_t *chunk_prefix = nullptr;
-    uint32_t max_len = 0;
-    ORCD_TRY(dictionary_sums(c, (const int64_t *)d_dict_off, dict_size, dict_total, (const int64_t *)d_idx,
-                             num_values, &chunk_prefix, &total, &max_len));
+    ORCD_TRY(dictionary_sums_launch(c, (const int64_t *)d_dict_off, dict_size, dict_total, (const int64_t *)d_idx,
+                                    num_values, &chunk_prefix, false));
     uint8_t *d_bytes = bytes_out;
+    if (out_dev) {
+        // The gather follows at once -- the device does not sit idle while the host looks at the
+        // first phase's verdict -- and writes no byte past the capacity, whatever the total is.
+        HIP_TRY(c, launch_dictionary_gather(c->stream, (const int64_t *)d_dict_off, (const uint8_t *)d_dict_bytes,
+                                            dict_size, dict_total, (const int64_t *)d_idx, num_values,
+                                            chunk_prefix, d_offsets, d_bytes, max_len, bytes_capacity));
+        ORCD_TRY(dictionary_sums_verdict(c, dict_total, num_values, chunk_prefix, &total, nullptr));
+        if (bytes_out && total > bytes_capacity) return ORCD_INVALID_ARGUMENT;
+        mark(c, 3);
+        return ORCD_OK;
+    }
+    ORCD_TRY(dictionary_sums_verdict(c, dict_total, num_values, chunk_prefix, &total, nullptr));
     if (bytes_out) {
         if (total > bytes_capacity) return ORCD_INVALID_ARGUMENT;
-        if (!out_dev) {
-            void *p;
-            ORCD_TRY(ensure(c, SLOT_OUT_B, total, &p));
-            d_bytes = (uint8_t *)p;
-        }
+        void *p;
+        ORCD_TRY(ensure(c, SLOT_OUT_B, total, &p));
+        d_bytes = (uint8_t *)p;
     }
     HIP_TRY(c, launch_dictionary_gather(c->stream, (const int64_t *)d_dict_off, (const uint8_t *)d_dict_bytes,
                                         dict_size, dict_total, (const int64_t *)d_idx, num_values,

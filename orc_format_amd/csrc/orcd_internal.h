@@ -311,7 +311,8 @@ hipError_t launch_dictionary_chunk_sums(hipStream_t st, const int64_t *dict_offs
 hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
                                     const uint8_t *dict_bytes, uint64_t dict_size, uint64_t dict_total,
                                     const int64_t *indices, uint64_t n, const uint64_t *chunk_prefix,
-                                    int64_t *offsets_out, uint8_t *bytes_out, uint32_t max_len);
+                                    int64_t *offsets_out, uint8_t *bytes_out, uint32_t max_len,
+                                    uint64_t capacity = ~0ull);
 
 // Null scatter: per-tile counts of valid rows, then (after an exclusive scan of the counts)
 // out[r] = dense[number of valid rows before r] for valid rows, zero for null rows -- or the same

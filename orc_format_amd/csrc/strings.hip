@@ -538,7 +538,7 @@ __global__ __launch_bounds__(DG_THREADS, SHORT ? 8 : 6) void dictionary_gather_k
     const int64_t *__restrict__ dict_offsets, const uint8_t *__restrict__ dict_bytes,
     uint64_t dict_total, uint64_t dict_size, const int64_t *__restrict__ indices, uint64_t n,
     const uint64_t *__restrict__ chunk_prefix, int64_t *__restrict__ offsets_out,
-    uint8_t *__restrict__ bytes_out) {
+    uint8_t *__restrict__ bytes_out, uint64_t capacity) {
     constexpr uint32_t IMG = SHORT ? DG_IMAGE : DG_IMAGE_LONG;
     __shared__ __attribute__((aligned(16))) uint8_t image_all[DG_WAVES][IMG + 32];
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
@@ -607,7 +607,9 @@ __global__ __launch_bounds__(DG_THREADS, SHORT ? 8 : 6) void dictionary_gather_k
             offsets_out[i] = (int64_t)off;
             if (i + 1 == n) offsets_out[n] = (int64_t)(off + len);
         }
-        if (!bytes_out) continue;  // offsets only
+        // offsets only; or bytes_out holds `capacity` bytes and the column has turned out longer
+        // (the host learns that from the total, after this launch)
+        if (!bytes_out || o1 > capacity) continue;
         const uint64_t total = o1 - o0;
         // (the scanned sums and the wave scan agree unless the sums were not of these values)
         // (... and the image's addressing is 32-bit: 2 GiB and more go the slow way)
@@ -750,7 +752,7 @@ hipError_t launch_dictionary_chunk_sums(hipStream_t st, const int64_t *dict_offs
 hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
                                     const uint8_t *dict_bytes, uint64_t dict_size, uint64_t dict_total,
                                     const int64_t *indices, uint64_t n, const uint64_t *chunk_prefix,
-                                    int64_t *offsets_out, uint8_t *bytes_out, uint32_t max_len) {
+                                    int64_t *offsets_out, uint8_t *bytes_out, uint32_t max_len, uint64_t capacity) {
     if (n == 0) return hipSuccess;
     const uint64_t chunks = (n + 63) / 64;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((chunks + DG_WAVES - 1) / DG_WAVES, 256 * 4);  // workgroups take chunks in turn
@@ -759,7 +761,7 @@ hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
     const bool is_short = max_len <= DG_SHORT_LEN;  // max_len: of the dictionary's entries (dictionary_max_len_kernel)
 #define ORCD_DG_LAUNCH(L, S)                                                                       \
     dictionary_gather_kernel<L, S><<<blocks, DG_THREADS, (L) ? (size_t)lds : 0, st>>>(               \
-        dict_offsets, dict_bytes, dict_total, dict_size, indices, n, chunk_prefix, offsets_out, bytes_out)
+        dict_offsets, dict_bytes, dict_total, dict_size, indices, n, chunk_prefix, offsets_out, bytes_out, capacity)
     if (in_lds && is_short) ORCD_DG_LAUNCH(true, true);
     else if (in_lds) ORCD_DG_LAUNCH(true, false);
     else if (is_short) ORCD_DG_LAUNCH(false, true);

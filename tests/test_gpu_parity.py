@@ -573,3 +573,47 @@ def test_deserialize_module(golden_dir, expected):
             v, off, data = de.deserialize_str_array(column)
             got = assemble.scatter(v, de.strings(off, data))
         assert got == want, name
+
+
+def test_dictionary_gather_on_device_with_a_capacity(oracle):
+    """Device pointers in and out: the gather is launched before the host knows the column's size,
+    so the capacity has to hold by the kernel's own check -- a buffer of exactly the size works, one
+    that is too small gives ORCD_INVALID_ARGUMENT and not a byte past its end is written; an index
+    past the dictionary is still reported."""
+    import torch
+    from orc_format_amd import _native as N, default_context
+    ctx = default_context()
+    lib = N.lib()
+    rng = np.random.default_rng(77)
+    for max_len in (20, 90):   # both kernels
+        lens = rng.integers(0, max_len + 1, size=700)
+        doff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        dbytes = rng.integers(0, 256, size=int(doff[-1]), dtype=np.uint8)
+        idx = rng.integers(0, lens.size, size=200_003)
+        rc, o_ref, b_ref = oracle.string_dictionary(doff, dbytes.tobytes(), idx)
+        assert rc == 0
+        total = int(o_ref[-1])
+        d_off, d_bytes, d_idx = (torch.from_numpy(a).cuda() for a in (doff, dbytes, idx))
+        offsets = torch.empty(idx.size + 1, dtype=torch.int64, device="cuda")
+        GUARD = 4096
+        for cap in (total, total - 1, total // 2, 0):
+            out = torch.full((total + GUARD,), 0xA5, dtype=torch.uint8, device="cuda")
+            rc = lib.orcd_string_dictionary_decode(ctx.handle, d_off.data_ptr(), d_bytes.data_ptr(), lens.size,
+                                                   d_idx.data_ptr(), idx.size, offsets.data_ptr(), out.data_ptr(),
+                                                   cap, N.IN_DEVICE | N.OUT_DEVICE)
+            torch.cuda.synchronize()
+            if cap >= total:
+                assert rc == 0
+                assert np.array_equal(offsets.cpu().numpy(), o_ref)
+                assert out[:total].cpu().numpy().tobytes() == b_ref.tobytes()
+            else:
+                assert rc == 102, (cap, rc)  # ORCD_INVALID_ARGUMENT
+            assert bool((out[cap:] == 0xA5).all()), cap
+        bad = idx.copy()
+        bad[100_000] = lens.size
+        d_bad = torch.from_numpy(bad).cuda()
+        out = torch.empty(total + GUARD, dtype=torch.uint8, device="cuda")
+        rc = lib.orcd_string_dictionary_decode(ctx.handle, d_off.data_ptr(), d_bytes.data_ptr(), lens.size,
+                                               d_bad.data_ptr(), bad.size, offsets.data_ptr(), out.data_ptr(),
+                                               out.numel(), N.IN_DEVICE | N.OUT_DEVICE)
+        assert rc == 1  # ORCD_OUT_OF_SPEC (deserialize.rs:162)
