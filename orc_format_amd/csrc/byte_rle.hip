@@ -427,15 +427,18 @@ __device__ __forceinline__ uint32_t stream_byte(const uint8_t *s, uint64_t src, 
 
 // Booleans: every decoded byte is 8 values, most significant bit first (boolean_rle.rs:98,118).
 // A wavefront takes a tile of BOOL_TILE decoded bytes in BOOL_STEPS steps (a tile costs three
-// dependent memory round trips -- window index, runs, stream bytes -- whatever its size, and
-// with small tiles those round trips, not the bytes, bound the kernel); in a step lane i owns bytes
-// 128*step + 2*i and the next one, i.e. 16 values, so that each store instruction writes 1 KiB of
-// consecutive values.  The runs that overlap the tile are loaded once, one per lane, and every
-// lane then finds the runs of its bytes with register shuffles (a tile overlapped by more than 64
-// runs falls back to per-lane walks of the run table).  out_bytes: one byte per value;
-// out_bitmap: the same bits least-significant-first; *set_bits: the number of ones.
+// dependent memory round trips -- window index, runs, stream bytes -- whatever its size; tiles of
+// half and of twice the size both measured slower); in a step lane i owns bytes 128*step + 2*i
+// and the next one, i.e. 16 values, so that each store instruction writes 1 KiB of consecutive
+// values.  The runs that overlap the tile are loaded once, one per lane, the stream bytes between
+// the first run's source and the last one's are staged in LDS with one or two 16-byte loads per
+// lane, and every lane then finds the runs of its bytes with register shuffles and its bytes in
+// LDS (a tile overlapped by more than 64 runs falls back to per-lane walks of the run table).
+// out_bytes: one byte per value; out_bitmap: the same bits least-significant-first; *set_bits:
+// the number of ones.
 constexpr uint32_t BOOL_STEPS = 8;
 constexpr uint32_t BOOL_TILE = 128 * BOOL_STEPS;
+constexpr uint32_t BOOL_SLICE = BOOL_TILE + 384;  // stream bytes of a tile that a wavefront stages in LDS
 constexpr uint32_t BOOL_COUNT_SLOTS = 64;  // counters of ones, BOOL_COUNT_PITCH words apart
 constexpr uint32_t BOOL_COUNT_PITCH = BOOL_COUNT_BYTES / 8 / BOOL_COUNT_SLOTS;
 
@@ -447,11 +450,27 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
     const uint64_t num_bytes = (num_bits + 7) >> 3;  // decoded bytes wanted
     const uint64_t n_tiles = (num_bytes + BOOL_TILE - 1) / BOOL_TILE;
     const uint32_t lane = threadIdx.x & 63;
+    // A decoded byte's eight values, one per byte, most significant bit first: a table look-up in
+    // LDS (the kernel is bound by the instructions it issues, and the LDS pipe has nothing else to do).
+    __shared__ uint64_t spread[256];
+    __shared__ __attribute__((aligned(16))) uint8_t slice_all[4][BOOL_SLICE + 16];
+    uint8_t *slice = slice_all[threadIdx.x >> 6];
+    {
+        const uint32_t b = threadIdx.x & 255;
+        // replicate the byte, keep one bit per copy, turn "non-zero" into 1
+        const uint32_t rep = b * 0x01010101u;
+        const uint32_t lo4 = (((rep & 0x10204080u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u;
+        const uint32_t hi4 = (((rep & 0x01020408u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u;
+        spread[b] = ((uint64_t)hi4 << 32) | lo4;
+        __syncthreads();
+    }
     const bool bytes_aligned = (((uintptr_t)out_bytes) & 15) == 0;
     const bool bitmap_aligned = (((uintptr_t)out_bitmap) & 1) == 0;
     uint32_t ones = 0;
     // Grid-stride over tiles: the count of ones costs one atomic per wavefront.  (Fetching the
-    // window index and the runs of the following tiles ahead of time measured no faster.)
+    // window index and the runs of the following tiles ahead of time measured no faster, before
+    // and after the stream bytes went through LDS: the kernel is bound by what it issues and
+    // stores, not by the three dependent loads of a tile.)
     for (uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles;
          tile += (uint64_t)gridDim.x * 4) {
         const uint64_t tile_base = tile * BOOL_TILE;
@@ -466,113 +485,13 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
         if (r_lo > r_hi) r_lo = r_hi;
         // a tile whose values are all wanted needs no masking of a partial last byte
         const bool full = (tile_base + BOOL_TILE) * 8 <= num_bits;
-        uint32_t mm[BOOL_STEPS];  // per step: this lane's two decoded bytes, the first in bits 0..7
-        if (r_hi - r_lo <= 64) {
-            // lane k holds run r_lo + k: its start relative to the tile (negative for a run that
-            // began before it) and its source relative to the first run's
-            int32_t my_rel = 0x7FFFFFFF;
-            uint64_t my_src = 0;
-            if (lane < r_hi - r_lo) {
-                const ByteRun run = runs[r_lo + lane];
-                my_rel = (int32_t)(int64_t)(run.out_off - tile_base);
-                my_src = run.src;
-            }
-            const uint64_t src0 = readfirst_u64(my_src) & PAYLOAD_MASK;
-            // offset from src0 (runs of one tile lie within 64 * 131 stream bytes), run flag on top
-            const uint32_t my_srel = (uint32_t)((my_src & PAYLOAD_MASK) - src0) |
-                                     ((my_src & BR_IS_RUN) ? 0x80000000u : 0u);
-            // all addressing below is 32-bit, relative to s + src0
-            const uint8_t *sb = s + src0;
-            const uint32_t skew = (uint32_t)((uintptr_t)sb & 3);
-            const uint32_t *sw = (const uint32_t *)(sb - skew);  // the aligned dword at or before s + src0
-            const uint64_t avail = len > src0 ? len - src0 : 0;  // stream bytes from src0 on
-            // the last offset a load may use: every byte that is wanted lies inside a run, and the
-            // scan has checked every run against the stream's length, so only bytes past the last
-            // value (which are masked out below) can point further -- those are clamped
-            const uint32_t last = (avail > 0xFFFF0000ull ? 0xFFFF0000u : (avail ? (uint32_t)avail - 1u : 0u)) + skew;
-            // A byte at tile position q inside run k comes from offset base_k + (q & mask_k):
-            // a literal's bytes follow one another (base = source - start, mask = all ones), a
-            // run's all come from its one value byte (base = source, mask = 0).
-            const uint32_t my_mask = (my_srel >> 31) ? 0u : 0xFFFFFFFFu;
-            const uint32_t my_base = (my_srel & 0x7FFFFFFFu) + skew - ((uint32_t)my_rel & my_mask);
-            uint32_t boff[BOOL_STEPS][2];
-#pragma unroll
-            for (uint32_t step = 0; step < BOOL_STEPS; step++) {
-                const int32_t p = (int32_t)(128 * step + 2 * lane);
-                // The runs that hold the step's first and last byte: the starts ascend over the
-                // lanes, so the number of starts at or below a position is a ballot away.
-                const int32_t p_first = (int32_t)(128 * step);
-                const uint32_t kf = (uint32_t)__popcll(__ballot(my_rel <= p_first)) - 1u;
-                const uint32_t kl = (uint32_t)__popcll(__ballot(my_rel <= p_first + 127)) - 1u;
-                int32_t rel_n;
-                uint32_t base_k, base_n, mask_k, mask_n;
-                if (kl <= kf + 1) {
-                    // at most two runs under the step (runs of a hundred bytes and more are the
-                    // common case): their fields are wave-uniform, no lane has to search
-                    const int a = __builtin_amdgcn_readfirstlane((int)kf), b = (a + 1) & 63;
-                    rel_n = a == 63 ? 0x7FFFFFFF : __builtin_amdgcn_readlane(my_rel, b);
-                    base_k = __builtin_amdgcn_readlane(my_base, a);
-                    base_n = __builtin_amdgcn_readlane(my_base, b);
-                    mask_k = __builtin_amdgcn_readlane(my_mask, a);
-                    mask_n = __builtin_amdgcn_readlane(my_mask, b);
-                } else {
-                    // largest k with rel[k] <= p (lanes past the last run hold INT_MAX; rel[0] <= 0)
-                    int k = 0;
-#pragma unroll
-                    for (int sft = 32; sft >= 1; sft >>= 1) {
-                        const int32_t v = __shfl(my_rel, k + sft);
-                        if (v <= p) k += sft;
-                    }
-                    rel_n = __shfl(my_rel, (k + 1) & 63);
-                    if (k == 63) rel_n = 0x7FFFFFFF;  // no run after the 64th
-                    base_k = __shfl(my_base, k);
-                    base_n = __shfl(my_base, (k + 1) & 63);
-                    mask_k = __shfl(my_mask, k);
-                    mask_n = __shfl(my_mask, (k + 1) & 63);
-                }
-#pragma unroll
-                for (uint32_t h = 0; h < 2; h++) {
-                    const int32_t q = p + (int32_t)h;
-                    const bool next = q >= rel_n;  // runs are not empty: the next byte is in k or k + 1
-                    const uint32_t off = (next ? base_n : base_k) + ((uint32_t)q & (next ? mask_n : mask_k));
-                    boff[step][h] = off < last ? off : last;
-                }
-            }
-            // all the tile's stream loads go out together (as aligned dwords: a byte-sized load
-            // costs the memory pipeline as much per lane), then the bytes are picked out
-            uint32_t word[BOOL_STEPS][2];
-#pragma unroll
-            for (uint32_t step = 0; step < BOOL_STEPS; step++) {
-                word[step][0] = avail ? sw[boff[step][0] >> 2] : 0u;
-                const bool same = (boff[step][1] >> 2) == (boff[step][0] >> 2);
-                word[step][1] = (!same && avail) ? sw[boff[step][1] >> 2] : 0u;
-            }
-#pragma unroll
-            for (uint32_t step = 0; step < BOOL_STEPS; step++) {
-                const bool same = (boff[step][1] >> 2) == (boff[step][0] >> 2);
-                const uint32_t w1 = same ? word[step][0] : word[step][1];
-                const uint32_t b0 = (word[step][0] >> (8 * (boff[step][0] & 3))) & 0xFFu;
-                const uint32_t b1 = (w1 >> (8 * (boff[step][1] & 3))) & 0xFFu;
-                mm[step] = b0 | (b1 << 8);
-            }
-        } else {
-            RunCursor cur = {s, len, runs, n_runs, 0, {0, 0}, 0, 0};
-            for (uint32_t step = 0; step < BOOL_STEPS; step++) {
-                const uint64_t o = tile_base + 128 * step + 2 * lane;
-                mm[step] = 0;
-                if (o < num_bytes) {
-                    cur.find(win_first, o);
-                    mm[step] = cur.byte_at(o);
-                    if (o + 1 < num_bytes) mm[step] |= cur.byte_at(o + 1) << 8;
-                }
-            }
-        }
-#pragma unroll
-        for (uint32_t step = 0; step < BOOL_STEPS; step++) {
+        // the values of one step: this lane's two decoded bytes (the first in bits 0..7) counted,
+        // turned into bitmap bits and into one byte per value, and stored
+        auto emit = [&](uint32_t step, uint32_t two_in) {
+            uint32_t two = two_in;
             const uint64_t o = tile_base + 128 * step + 2 * lane;
-            uint32_t two = mm[step];
             if (!full) {
-                if (o >= num_bytes) break;
+                if (o >= num_bytes) return;
                 // clear the bytes and bits past the last value
                 const uint64_t first = o << 3;
                 const uint64_t left = num_bits - first;  // > 0: o < num_bytes
@@ -591,15 +510,8 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
                 }
             }
             if (out_bytes) {
-                uint64_t word[2];
-#pragma unroll
-                for (uint32_t k = 0; k < 2; k++) {  // byte j of the word = bit (7 - j) of the decoded byte
-                    // replicate the byte, keep one bit per copy, turn "non-zero" into 1
-                    const uint32_t rep = __builtin_amdgcn_perm(two, two, k ? 0x01010101u : 0u);  // byte k, four times
-                    const uint32_t lo4 = (((rep & 0x10204080u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u;
-                    const uint32_t hi4 = (((rep & 0x01020408u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u;
-                    word[k] = ((uint64_t)hi4 << 32) | lo4;
-                }
+                // byte j of a word = bit (7 - j) of the decoded byte
+                const uint64_t word[2] = {spread[two & 0xFFu], spread[(two >> 8) & 0xFFu]};
                 const uint64_t first = o << 3;
                 uint8_t *dst = out_bytes + first;
                 if ((full || first + 16 <= num_bits) && bytes_aligned) {
@@ -612,6 +524,119 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
                     for (uint32_t j = 0; j < 16 && first + j < num_bits; j++)
                         dst[j] = (uint8_t)(word[j >> 3] >> (8 * (j & 7)));
                 }
+            }
+        };
+        if (r_hi - r_lo <= 64) {
+            // lane k holds run r_lo + k: its start relative to the tile (negative for a run that
+            // began before it) and its source relative to the first run's
+            int32_t my_rel = 0x7FFFFFFF;
+            uint64_t my_src = 0;
+            if (lane < r_hi - r_lo) {
+                const ByteRun run = runs[r_lo + lane];
+                my_rel = (int32_t)(int64_t)(run.out_off - tile_base);
+                my_src = run.src;
+            }
+            const uint64_t src0 = readfirst_u64(my_src) & PAYLOAD_MASK;
+            // offset from src0 (runs of one tile lie within 64 * 131 stream bytes), run flag on top
+            const uint32_t my_srel = (uint32_t)((my_src & PAYLOAD_MASK) - src0) |
+                                     ((my_src & BR_IS_RUN) ? 0x80000000u : 0u);
+            // all addressing below is 32-bit, relative to s + src0
+            const uint8_t *sb = s + src0;
+            const uint64_t avail = len > src0 ? len - src0 : 0;  // stream bytes from src0 on
+            // The stream bytes the tile needs lie between the first run's source and the last
+            // run's (a literal's payload is at most 128 bytes, a run's one): they are fetched once,
+            // 16 bytes per lane, into this wavefront's slice of LDS, and every byte is then picked
+            // from there.  (Two dword loads per lane and step -- 16 a tile, for 2 bytes each --
+            // kept the memory pipeline busier than the output the tile writes.)  64 runs of a tile
+            // span at most BOOL_TILE + 127 + 128 + 64 bytes.
+            const uint32_t n_live = r_hi - r_lo;
+            const uint32_t srel_last = __builtin_amdgcn_readlane(my_srel, n_live ? (int)n_live - 1 : 0);
+            uint64_t span = n_live ? (uint64_t)(srel_last & 0x7FFFFFFFu) + ((srel_last >> 31) ? 1u : 128u) : 0;
+            if (span > avail) span = avail;
+            const uint32_t skew = (uint32_t)((uintptr_t)sb & 15);
+            if (span + skew <= BOOL_SLICE) {
+                const uint4 *src16 = (const uint4 *)(sb - skew);
+                const uint32_t n16 = (uint32_t)((span + skew + 15) >> 4);  // <= BOOL_SLICE / 16 + 1
+                constexpr uint32_t ROUNDS = (BOOL_SLICE / 16 + 1 + 63) / 64;
+                uint4 c[ROUNDS];
+#pragma unroll
+                for (uint32_t r = 0; r < ROUNDS; r++)
+                    if (lane + 64 * r < n16) c[r] = src16[lane + 64 * r];
+#pragma unroll
+                for (uint32_t r = 0; r < ROUNDS; r++)
+                    if (lane + 64 * r < n16) ((uint4 *)slice)[lane + 64 * r] = c[r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // the last offset a look-up may use: every byte that is wanted lies inside a run,
+                // and the scan has checked every run against the stream's length, so only bytes
+                // past the last value (which are masked out below) can point further -- those are
+                // clamped
+                const uint32_t last = (span ? (uint32_t)span - 1u : 0u) + skew;
+                // A byte at tile position q inside run k comes from offset base_k + (q & mask_k):
+                // a literal's bytes follow one another (base = source - start, mask = all ones), a
+                // run's all come from its one value byte (base = source, mask = 0).
+                const uint32_t my_mask = (my_srel >> 31) ? 0u : 0xFFFFFFFFu;
+                const uint32_t my_base = (my_srel & 0x7FFFFFFFu) + skew - ((uint32_t)my_rel & my_mask);
+#pragma unroll
+                for (uint32_t step = 0; step < BOOL_STEPS; step++) {
+                    const int32_t p = (int32_t)(128 * step + 2 * lane);
+                    // The runs that hold the step's first and last byte: the starts ascend over the
+                    // lanes, so the number of starts at or below a position is a ballot away.
+                    const int32_t p_first = (int32_t)(128 * step);
+                    const uint32_t kf = (uint32_t)__popcll(__ballot(my_rel <= p_first)) - 1u;
+                    const uint32_t kl = (uint32_t)__popcll(__ballot(my_rel <= p_first + 127)) - 1u;
+                    int32_t rel_n;
+                    uint32_t base_k, base_n, mask_k, mask_n;
+                    if (kl <= kf + 1) {
+                        // at most two runs under the step (runs of a hundred bytes and more are the
+                        // common case): their fields are wave-uniform, no lane has to search
+                        const int a = __builtin_amdgcn_readfirstlane((int)kf), b = (a + 1) & 63;
+                        rel_n = a == 63 ? 0x7FFFFFFF : __builtin_amdgcn_readlane(my_rel, b);
+                        base_k = __builtin_amdgcn_readlane(my_base, a);
+                        base_n = __builtin_amdgcn_readlane(my_base, b);
+                        mask_k = __builtin_amdgcn_readlane(my_mask, a);
+                        mask_n = __builtin_amdgcn_readlane(my_mask, b);
+                    } else {
+                        // largest k with rel[k] <= p (lanes past the last run hold INT_MAX; rel[0] <= 0)
+                        int k = 0;
+#pragma unroll
+                        for (int sft = 32; sft >= 1; sft >>= 1) {
+                            const int32_t v = __shfl(my_rel, k + sft);
+                            if (v <= p) k += sft;
+                        }
+                        rel_n = __shfl(my_rel, (k + 1) & 63);
+                        if (k == 63) rel_n = 0x7FFFFFFF;  // no run after the 64th
+                        base_k = __shfl(my_base, k);
+                        base_n = __shfl(my_base, (k + 1) & 63);
+                        mask_k = __shfl(my_mask, k);
+                        mask_n = __shfl(my_mask, (k + 1) & 63);
+                    }
+                    uint32_t two = 0;
+#pragma unroll
+                    for (uint32_t h = 0; h < 2; h++) {
+                        const int32_t q = p + (int32_t)h;
+                        const bool next = q >= rel_n;  // runs are not empty: the next byte is in k or k + 1
+                        const uint32_t off = (next ? base_n : base_k) + ((uint32_t)q & (next ? mask_n : mask_k));
+                        two |= (uint32_t)slice[off < last ? off : last] << (8 * h);
+                    }
+                    emit(step, two);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the next tile's bytes come after these look-ups
+                continue;
+            }
+        }
+        {
+            RunCursor cur = {s, len, runs, n_runs, 0, {0, 0}, 0, 0};
+            for (uint32_t step = 0; step < BOOL_STEPS; step++) {
+                const uint64_t o = tile_base + 128 * step + 2 * lane;
+                uint32_t two = 0;
+                if (o < num_bytes) {
+                    cur.find(win_first, o);
+                    two = cur.byte_at(o);
+                    if (o + 1 < num_bytes) two |= cur.byte_at(o + 1) << 8;
+                }
+                emit(step, two);
             }
         }
     }
