@@ -6,6 +6,8 @@
 // crate's: run headers form a serial chain, so they are walked once per *segment* (the bytes
 // between two caller-supplied entry points) by one lane each, and the values -- the bulk of the
 // bytes -- are then expanded by one wavefront per aligned window of 512 output values.
+#include <type_traits>
+
 #include "orcd_internal.h"
 #include "seg_scan.h"
 
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
 // ring and are parsed in full 64 at a time, which is also where their descriptors are staged.
 // Writes t.seg_count only; rlev2_publish_kernel turns that into the scan's inputs.
 constexpr uint32_t COOP_RING = 128;
+constexpr uint32_t COUNT_SLICE_BYTES = 48 << 10;  // stream bytes a wavefront of rlev2_count_staged_kernel holds
 
 __global__ __launch_bounds__(256) void rlev2_coop_count_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
@@ -575,6 +578,171 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_publish_kernel(uint32_t n_seg
     c.n_vals = 0;
     if (seg < n_seg) c = t.seg_count[seg];
     seg_publish(t, seg, n_seg, c.n_runs, c.last_len, c.status, c.n_vals);
+}
+
+// COUNT for streams of many small segments (short runs between close entry points): a wavefront
+// takes `group` neighbouring segments, copies the bytes they span -- one contiguous piece of the
+// stream -- into its slice of LDS with loads that write LDS themselves, and `group` of its lanes
+// then walk a segment each out of LDS.  The lane-per-segment walk of rlev2_scan_kernel spends a
+// load of its own per lane on every few headers, 64 cache lines per instruction; here every line
+// of the stream is fetched once, by a load that uses all of it, and a header costs two LDS reads.
+// With its bytes in LDS a wavefront is alone on its SIMD most of the time, and what a step then
+// costs is its instructions one after the other, every branch an empty instruction buffer: so
+// ShortRepeat and Direct runs, which such columns are made of and whose size follows from their
+// first two bytes, are sized side by side without the general parser and picked by selects (the
+// counting pass wants a run's descriptor and its end, a fraction of what parse_run works out), and
+// the descriptors go out one by one instead of through an LDS collector.  Delta and PatchedBase
+// runs go through parse_run on 16 bytes out of LDS.  A wavefront whose segments span more than its
+// slice walks them from memory.  Positions are 32-bit offsets from the span's start.
+// (5 * 10^8 values in 2.5 * 10^7 runs, 64 to a segment: 0.39 -> 0.23 ms.  How long the pass takes
+// is the number of times the chip's LDS fills with stream bytes times a segment's runs times a
+// step: 32 segments to a wavefront with half the slice, or 16, measured the same or slower.)
+// Writes t.seg_count only; rlev2_publish_kernel turns that into the scan's inputs.
+// Dynamic LDS per wavefront: slice_bytes + 32.
+__global__ __launch_bounds__(64) void rlev2_count_staged_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
+    const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
+    uint64_t *__restrict__ staged, uint32_t staged_cap, uint32_t group, uint32_t slice_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t cs_dyn[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+    const uint32_t slice_pitch = slice_bytes + 32;
+    uint8_t *slice = cs_dyn + (size_t)wave * slice_pitch;
+    const uint64_t first64 = ((uint64_t)blockIdx.x * n_waves + wave) * group;
+    if (first64 >= n_seg) return;  // whole wavefront; no workgroup barrier below
+    const uint32_t seg = (uint32_t)first64 + lane;
+    const bool valid = lane < group && seg < n_seg;
+    // a segment's bounds: as in rlev2_scan_kernel
+    uint64_t pos = (valid && entries && (seg > 0 || seg_ends)) ? entries[seg] : 0;
+    uint64_t end = (valid && entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
+    if (valid && seg_ends) end = seg_ends[seg];
+    const uint64_t limit = seg_ends ? (end < len ? end : len) : len;
+    const bool last_seg = seg + 1 == n_seg;
+    if (pos > len) pos = len;
+    uint32_t status = SEG_OK;
+    if (end > len || end < pos) status = SEG_MISALIGNED;
+    const bool walking = valid && status == SEG_OK && pos < end;
+    // what the walking lanes span
+    uint64_t lo = walking ? pos : ~0ull, hi = walking ? end : 0;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t ol = shfl64(lo, (int)lane ^ d), oh = shfl64(hi, (int)lane ^ d);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    lo = readfirstlane64(lo);
+    hi = readfirstlane64(hi);
+    const uint32_t skew = (uint32_t)((uintptr_t)(s + (hi > lo ? lo : 0)) & 15);
+    const bool in_lds = hi > lo && hi - lo + skew + 4 <= slice_bytes;
+    if (in_lds) {
+        const uintptr_t a0 = (uintptr_t)(s + lo) - skew, stop = (uintptr_t)(s + len);
+        // (three bytes past the span may be looked at with a header's four)
+        const uint32_t n16 = (uint32_t)((hi - lo + skew + 3 + 15) >> 4);
+        // loads that write LDS themselves, 1 KiB per instruction (lane i's 16 bytes land at the
+        // instruction's LDS address + 16 i): none of them waits for another or holds a register
+        for (uint32_t c0 = 0; c0 < n16; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            if (c < n16 && a0 + 16 * (uintptr_t)c < stop)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a0 + 16 * (uintptr_t)c),
+                                                 (__attribute__((address_space(3))) void *)(slice + 16 * c0), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    uint32_t n_runs = 0, last_len = 0;
+    uint64_t n_vals = 0;
+    // the descriptors go out one by one (eight bytes a run, eight runs to a 64-byte piece of a line
+    // that L2 puts together): collecting them in LDS first costs the walk more than it saves here
+    uint64_t *mine = staged + (uint64_t)seg * staged_cap;
+    const uint32_t cap_mine = (staged && valid) ? staged_cap : 0;
+    if (walking) {
+        const uint32_t *words = (const uint32_t *)slice;
+        // offsets from lo: below 2^32 when the span is in LDS; otherwise only while the segment is
+        // (a longer one stops as SEG_TOO_LONG would: the host sends such streams elsewhere)
+        uint32_t rel = (uint32_t)(pos - lo);
+        const uint32_t rel_end = (uint32_t)(end - lo);
+        const uint32_t rel_limit = limit - lo > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(limit - lo);
+        if ((!in_lds && (end - lo) > 0xFFFF0000ull) || end + 2 > RUN_PAYLOAD_MASK) status = SEG_TOO_LONG;
+        // (two copies of the loop, so that the one over LDS carries no test of where its bytes are)
+        auto walk = [&](auto from_lds) {
+            constexpr bool IN_LDS = decltype(from_lds)::value;
+            while (status == SEG_OK && rel < rel_end) {
+                const uint64_t p = lo + rel;  // the header's place in the stream
+                uint32_t h;
+                if (IN_LDS) {
+                    const uint32_t o = rel + skew;
+                    h = __builtin_amdgcn_alignbyte(words[(o >> 2) + 1], words[o >> 2], o & 3u);
+                } else {
+                    const uintptr_t a = (uintptr_t)(s + p), a4 = a & ~(uintptr_t)3;
+                    const uint32_t d0 = *(const uint32_t *)a4;
+                    const uint32_t d1 = *(const uint32_t *)(a4 + 4 < (uintptr_t)(s + len) ? a4 + 4 : a4);
+                    h = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)(a & 3));
+                }
+                const uint32_t kind = (h >> 6) & 3u;
+                if (kind > KIND_DIRECT) {
+                    // Delta and PatchedBase: variable-length fields decide where the run ends
+                    Window16 w;
+                    if (IN_LDS) {
+                        const uint32_t o = rel + skew, k = o >> 2, sh = o & 3u;
+                        // (up to 16 bytes past the span: whatever the slice holds there; a run that
+                        // needs them is found truncated by its end, as with load_window)
+                        const uint32_t w0 = words[k], w1 = words[k + 1], w2 = words[k + 2], w3 = words[k + 3], w4 = words[k + 4];
+                        w.lo = ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32) | __builtin_amdgcn_alignbyte(w1, w0, sh);
+                        w.hi = ((uint64_t)__builtin_amdgcn_alignbyte(w4, w3, sh) << 32) | __builtin_amdgcn_alignbyte(w3, w2, sh);
+                    } else {
+                        w = load_window(s, limit, p);
+                    }
+                    ParsedRun r;
+                    const uint32_t st = parse_run(w, s, limit, p, is_signed, r);
+                    if (st != SEG_OK) {
+                        status = st;
+                        break;
+                    }
+                    if (n_runs < cap_mine) mine[n_runs] = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes);
+                    n_runs++;
+                    n_vals += r.len;
+                    last_len = r.len;
+                    if (r.run_end - lo > 0xFFFFFFFFull) {
+                        status = SEG_MISALIGNED;  // (past every segment's end)
+                        break;
+                    }
+                    rel = (uint32_t)(r.run_end - lo);
+                    continue;
+                }
+                // both kinds worked out side by side and picked by selects: a wavefront that walks
+                // alone on its SIMD pays for every branch with an empty instruction buffer
+                const bool is_sr = kind == KIND_SHORT_REPEAT;
+                const uint32_t nbytes = ((h >> 3) & 7u) + 1u;                       // rle_v2.rs:283-301
+                const uint32_t code = (h >> 1) & 31u, t24 = code - 24u;              // Direct, rle_v2.rs:135-157
+                const uint32_t w_d = code <= 23u ? code + 1u : (t24 < 4u ? 26u + 2u * t24 : 8u + 8u * t24);  // width_from_code
+                const uint32_t len_d = (((h & 1u) << 8) | ((h >> 8) & 0xFFu)) + 1u;
+                const uint32_t rl = is_sr ? (h & 7u) + 3u : len_d;
+                const uint32_t width = is_sr ? nbytes * 8u : w_d;
+                const uint32_t hdr = is_sr ? 1u : 2u;
+                const uint32_t size = is_sr ? 1u + nbytes : 2u + ((w_d * len_d + 7u) >> 3);
+                if (size > rel_limit - rel) {  // (rel < rel_end <= rel_limit)
+                    status = SEG_TRUNCATED;
+                    break;
+                }
+                if (n_runs < cap_mine) mine[n_runs] = make_desc(p + hdr, kind, width, rl, 0, hdr);
+                n_runs++;
+                n_vals += rl;
+                last_len = rl;
+                rel += size;
+            }
+        };
+        if (in_lds) walk(std::true_type{});
+        else walk(std::false_type{});
+        if (status == SEG_OK && rel != rel_end && !last_seg) status = SEG_MISALIGNED;
+    }
+    if (valid) {
+        SegCount c;
+        c.n_runs = n_runs;
+        c.last_len = last_len;
+        c.status = status;
+        c.pad = 0;
+        c.n_vals = n_vals;
+        t.seg_count[seg] = c;
+    }
 }
 
 // EMIT for the segments whose descriptors the counting pass staged: a group of lanes per segment,
@@ -2819,6 +2987,22 @@ hipError_t launch_spec_publish(hipStream_t st, uint32_t *flag, ScanTotals *host_
 hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                               const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                               int is_signed, const SegTable &t, uint64_t *staged, uint32_t staged_cap) {
+    // Many small segments: a wavefront stages the bytes of 64 of them in LDS, or of 32 where 64
+    // would not fit with room to spare (see rlev2_count_staged_kernel).  One wavefront to a
+    // workgroup: three slices fit a compute unit.
+    const uint64_t avg = len / n_seg;
+    if (n_seg >= 4096 && len < 0xFFFF0000ull) {
+        uint32_t group = 0;
+        for (uint32_t g : {64u, 32u})
+            if (!group && avg * g * 11 / 10 + 64 <= COUNT_SLICE_BYTES) group = g;
+        if (group) {
+            const uint64_t n_waves = ((uint64_t)n_seg + group - 1) / group;
+            rlev2_count_staged_kernel<<<(uint32_t)n_waves, 64, COUNT_SLICE_BYTES + 32, st>>>(
+                stream, len, entries, seg_ends, n_seg, is_signed, t, staged, staged_cap, group, COUNT_SLICE_BYTES);
+            rlev2_publish_kernel<<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(n_seg, t);
+            return hipGetLastError();
+        }
+    }
     const uint32_t blocks = (n_seg + SEG_BLOCK - 1) / SEG_BLOCK;
     rlev2_scan_kernel<false><<<blocks, SEG_BLOCK, 0, st>>>(stream, len, entries, seg_ends, n_seg,
                                                           is_signed, t, nullptr, nullptr, nullptr, 0, 0,
