@@ -323,6 +323,7 @@ struct orcd_ctx {
     const char *last_kernel = "";  // the kernel that expanded the values of the last RLE v2 call
     float stripe_feed_ms = -1.0f, stripe_decode_ms = -1.0f;  // the last orcd_decode_stripe call (host clock)
     int spec_pref = ORCD_PATH_STRIDED;  // the speculative path that worked last, tried first
+    int selfplan_rest = 0;              // calls for which the plan is a pass of its own without asking (see attempt_planned)
     uint32_t spec_fail_streak = 0, spec_skip = 0;
     bool spec_flag_clean = false;  // the device word of SLOT_SPEC_FLAG is known to be zero
 };
@@ -859,8 +860,15 @@ int attempt_planned(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
     // window (10-bit deltas: 1.69 against 1.74 ms), slower above (16-bit: 1.83 against 1.79).
     // Segments of unequal run counts (stride_vals) are only for the first.
     const bool dense = len / n_win <= SELFPLAN_MAX_BYTES_PER_WINDOW;
-    const bool selfplan = (stride_vals || dense || !even) && !(((uintptr_t)d_out) & 15) &&
-                          rlev2_selfplan_shape((uint32_t)n_entries, (uint32_t)n_win, stride_vals);
+    bool selfplan = (stride_vals || dense || !even) && !(((uintptr_t)d_out) & 15) &&
+                    rlev2_selfplan_shape((uint32_t)n_entries, (uint32_t)n_win, stride_vals);
+    // (a context whose last such column was one the single launch gave up on and the separate pass
+    // decoded -- PatchedBase runs -- goes to that pass directly for a while)
+    if (selfplan && even && !stride_vals && c->selfplan_rest > 0) {
+        c->selfplan_rest--;
+        selfplan = false;
+    }
+    const bool tried_selfplan = selfplan;
     if (selfplan) {
         void *seg_table;
         ORCD_TRY(ensure(c, SLOT_GROUPS, rlev2_selfplan_table_bytes((uint32_t)n_entries), &seg_table));
@@ -900,7 +908,9 @@ int attempt_planned(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
     c->last_kernel = "rlev2_planned_values_kernel";
     const uint32_t stamp = next_stamp(c);
     HIP_TRY(c, launch_spec_publish(c->stream, flag, c->h_totals, stamp));
-    return spec_verdict(c, stamp, done);
+    ORCD_TRY(spec_verdict(c, stamp, done));
+    if (*done && tried_selfplan) c->selfplan_rest = 15;
+    return ORCD_OK;
 }
 
 int try_strided(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num_values,

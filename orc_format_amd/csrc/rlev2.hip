@@ -2732,6 +2732,10 @@ __global__ __launch_bounds__(256) void rlev2_selfplan_segments_kernel(
             p.first_win = (uint32_t)fw;
             p.n_win = (uint32_t)(fw_next - fw);
             p.h0 = s[e0];
+            // PatchedBase runs are not for the expansion behind this table (it would decode each
+            // header with the general parser, patches and all, in every wavefront's critical
+            // path): the plan as a pass of its own takes such a column a third faster
+            if ((p.h0 >> 6) == KIND_PATCHED_BASE) raise_flag(flag);
         }
     }
     table[seg] = p;
