@@ -136,15 +136,17 @@ const char *orcd_ctx_last_value_kernel(orcd_ctx *ctx);
  * stage and column) on stderr, with a wait for the GPU after every stage.  For benchmarks. */
 int orcd_ctx_last_stripe_ms(orcd_ctx *ctx, float *feed_ms, float *decode_ms);
 /* The host threads the library starts beside its callers' -- readers and copiers of a stripe's
- * bytes, the decompression threads of a compressed file -- come out of one budget for the whole
- * process, however many contexts and open files there are: ORCD_HELPER_THREADS from the
- * environment when set, else the CPUs the process may use (OMP_NUM_THREADS where a launcher sets
- * it, else the hardware's count) divided by the ranks of the node (LOCAL_WORLD_SIZE, else
- * WORLD_SIZE), at least 2, at most 64.  An operation that finds the budget spent does its work on
- * the calling thread.  Reports the budget, the helpers at work this moment and the most there ever
- * were at once (any pointer may be null).  The helpers of a context bind themselves to the CPUs
- * of the NUMA node its GPU is attached to where /sys says which (ORCD_NUMA_BIND=0: never).  No
- * counterpart in the crate, which is single-threaded. */
+ * bytes, the decompression threads of a compressed file -- are one pool for the whole process,
+ * however many contexts and open files there are: as many threads as ORCD_HELPER_THREADS says
+ * when it is set, else the CPUs the process may use (OMP_NUM_THREADS where a launcher sets it,
+ * else the hardware's count) divided by the ranks of the node (LOCAL_WORLD_SIZE, else
+ * WORLD_SIZE), at least 2, at most 64.  An operation works on its calling thread and is joined
+ * by the pool's idle threads, which go to whichever operation has the fewest: callers that feed
+ * stripes side by side share them evenly.  Reports the size of the pool, the helpers at work this
+ * moment and the most there ever were at once (any pointer may be null).  The threads bind
+ * themselves to the CPUs of the NUMA node that the process's first context's GPU is attached to,
+ * where /sys says which (ORCD_NUMA_BIND=0: never).  No counterpart in the crate, which is
+ * single-threaded. */
 int orcd_helper_threads(int *budget, int *in_use, int *peak);
 /* Text of the last HIP runtime error seen by this context (after ORCD_HIP_ERROR). */
 const char *orcd_ctx_last_hip_error(orcd_ctx *ctx);

@@ -117,83 +117,14 @@ struct BlockCache {
     }
 };
 
-// The host threads of a context that move large transfers (see run_chunked): started on first
-// use, parked between transfers, joined when the context is destroyed.
-struct CopyThreads {
-    cpu_set_t bind;          // the CPUs next to the device's memory (see orcd_internal_numa_cpus)
-    bool have_bind = false;
-    std::vector<std::thread> threads;  // thread k serves as worker k + 1; the caller is worker 0
-    std::mutex m;
-    std::condition_variable wake, done;
-    std::function<void(int)> job;
-    uint64_t generation = 0;
-    int n_active = 0, pending = 0;
-    bool stop = false;
-
-    void serve(int t) {
-        if (have_bind) (void)pthread_setaffinity_np(pthread_self(), sizeof(bind), &bind);  // (best effort)
-        uint64_t seen = 0;
-        for (;;) {
-            std::function<void(int)> fn;
-            bool mine;
-            {
-                std::unique_lock<std::mutex> lock(m);
-                wake.wait(lock, [&] { return stop || generation != seen; });
-                if (stop) return;
-                seen = generation;
-                mine = t < n_active;
-                fn = job;
-            }
-            if (!mine) continue;
-            fn(t);
-            std::lock_guard<std::mutex> lock(m);
-            if (--pending == 0) done.notify_one();
-        }
-    }
-    // as many threads as can be had, up to `want`; returns how many there are
-    int ensure(int want) {
-        while ((int)threads.size() < want) {
-            const int t = (int)threads.size() + 1;
-            try {
-                threads.emplace_back([this, t] { serve(t); });
-            } catch (...) {
-                break;
-            }
-        }
-        return (int)threads.size();
-    }
-    // fn(0) here and fn(1..n-1) on the threads; returns when all are done (n - 1 <= threads.size())
-    void run(int n, const std::function<void(int)> &fn) {
-        {
-            std::lock_guard<std::mutex> lock(m);
-            job = fn;
-            n_active = n;
-            pending = n - 1;
-            generation++;
-        }
-        wake.notify_all();
-        fn(0);
-        std::unique_lock<std::mutex> lock(m);
-        done.wait(lock, [&] { return pending == 0; });
-    }
-    ~CopyThreads() {
-        {
-            std::lock_guard<std::mutex> lock(m);
-            stop = true;
-        }
-        wake.notify_all();
-        for (auto &th : threads) th.join();
-    }
-};
-
-// What one party needs to move large transfers: pinned chunks, an event per chunk, parked threads.
+// What one party needs to move large transfers: pinned chunks and an event per chunk (the threads
+// are the process's helpers, orcd_internal_parallel_run).
 // The calling thread of a context has one set; the background reader of orcd_stripe_prefetch has
 // another, with a stream of its own.
 struct StageSet {
     uint8_t *h_stage[N_READERS] = {};  // pinned chunks, allocated on first use
     hipEvent_t ev_stage[N_READERS] = {};
     bool stage_busy[N_READERS] = {};   // a copy out of the chunk was queued and not yet waited for
-    CopyThreads *copy_threads = nullptr;
     hipStream_t stream = nullptr;      // where its copies are queued (null: the context's stream)
     void release() {
         for (int i = 0; i < N_READERS; i++) {
@@ -202,8 +133,6 @@ struct StageSet {
             h_stage[i] = nullptr;
             ev_stage[i] = nullptr;
         }
-        delete copy_threads;
-        copy_threads = nullptr;
     }
 };
 
@@ -396,31 +325,17 @@ int run_chunked(orcd_ctx *c, StageSet &ss, uint64_t len, Step step) {
     uint64_t chunk = (len / N_READERS + CHUNK_MIN - 1) / CHUNK_MIN * CHUNK_MIN;
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, CHUNK_MIN), STAGE_CHUNK);
     const uint64_t n_chunks = (len + chunk - 1) / chunk;
-    int n_threads = (int)std::min<uint64_t>(N_READERS, n_chunks);
-    // (the helpers beside this thread come out of the process's budget, orcd_helper_threads)
-    struct Lease {
-        int n;
-        ~Lease() { orcd_internal_helpers_release(n); }
-    } lease{n_threads > 1 ? orcd_internal_helpers_lease(n_threads - 1) : 0};
-    n_threads = 1 + lease.n;
-    if (n_threads > 1) {
-        if (!ss.copy_threads) {
-            ss.copy_threads = new (std::nothrow) CopyThreads();
-            if (ss.copy_threads && c->have_numa_cpus) {
-                ss.copy_threads->bind = c->numa_cpus;
-                ss.copy_threads->have_bind = true;
-            }
-        }
-        n_threads = ss.copy_threads ? std::min(n_threads, ss.copy_threads->ensure(n_threads - 1) + 1) : 1;
-    }
+    const int n_threads = (int)std::min<uint64_t>(N_READERS, n_chunks);
     std::atomic<int> status{ORCD_OK};
     std::atomic<int> hip_status{(int)hipSuccess};
+    std::atomic<uint64_t> next{0};
+    // worker t owns pinned chunk t; the chunks of the transfer go to whoever is free
     auto worker = [&](int t) {
         if (hipSetDevice(c->device) != hipSuccess) {
             status = ORCD_HIP_ERROR;
             return;
         }
-        for (uint64_t k = (uint64_t)t; k < n_chunks && status == ORCD_OK; k += (uint64_t)n_threads) {
+        for (uint64_t k; (k = next.fetch_add(1)) < n_chunks && status == ORCD_OK;) {
             const uint64_t pos = k * chunk, n = std::min<uint64_t>(chunk, len - pos);
             hipError_t e = hipSuccess;
             const int rc = step(t, pos, n, &e);
@@ -431,11 +346,8 @@ int run_chunked(orcd_ctx *c, StageSet &ss, uint64_t len, Step step) {
             }
         }
     };
-    if (n_threads <= 1) {
-        if (n_chunks) worker(0);
-    } else {
-        ss.copy_threads->run(n_threads, worker);
-    }
+    // (this thread and whatever helpers the process's pool can spare, orcd_helper_threads)
+    if (n_chunks) orcd_parallel(n_threads - 1, worker);
     if (status != ORCD_OK) {
         if (hip_status != (int)hipSuccess) c->last_hip = (hipError_t)hip_status.load();
         (void)hipStreamSynchronize(st);  // queued copies still use the pinned chunks
@@ -1130,6 +1042,7 @@ int orcd_ctx_create(int device_id, orcd_ctx **out) try {
         char bus[64] = {0};
         if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device_id) == hipSuccess)
             c->have_numa_cpus = orcd_internal_numa_cpus(bus, &c->numa_cpus, sizeof(c->numa_cpus)) != 0;
+            if (c->have_numa_cpus) orcd_internal_pool_bind(&c->numa_cpus, sizeof(c->numa_cpus));
     }
     *out = c;
     return ORCD_OK;
@@ -2250,27 +2163,15 @@ constexpr uint64_t PINNED_READ_MIN = 4u << 20;  // smaller regions are read the 
 int read_in_slices(orcd_file *file, uint64_t off, uint64_t len, uint8_t *dst) {
     const uint64_t slice = ((len + PINNED_READERS - 1) / PINNED_READERS + 4095) & ~(uint64_t)4095;
     int status[PINNED_READERS];
-    for (int i = 0; i < PINNED_READERS; i++) status[i] = -1;  // -1: nobody has read this slice yet
-    std::vector<std::thread> threads;
-    auto work = [&](int i) {
-        const uint64_t lo = std::min<uint64_t>(len, (uint64_t)i * slice), hi = std::min<uint64_t>(len, lo + slice);
-        status[i] = hi > lo ? orcd_file_read_at(file, off + lo, hi - lo, dst + lo) : ORCD_OK;
-    };
-    struct Lease {
-        int n;
-        ~Lease() { orcd_internal_helpers_release(n); }
-    } lease{orcd_internal_helpers_lease(PINNED_READERS - 1)};
-    for (int i = 1; i <= lease.n; i++) {
-        try {
-            threads.emplace_back(work, i);
-        } catch (...) {
-            break;
+    for (int i = 0; i < PINNED_READERS; i++) status[i] = ORCD_OK;
+    std::atomic<int> next{0};
+    // (this thread and whatever helpers the process's pool can spare take the slices in turn)
+    orcd_parallel(PINNED_READERS - 1, [&](int) {
+        for (int i; (i = next.fetch_add(1)) < PINNED_READERS;) {
+            const uint64_t lo = std::min<uint64_t>(len, (uint64_t)i * slice), hi = std::min<uint64_t>(len, lo + slice);
+            if (hi > lo) status[i] = orcd_file_read_at(file, off + lo, hi - lo, dst + lo);
         }
-    }
-    work(0);
-    for (auto &th : threads) th.join();
-    for (int i = 1; i < PINNED_READERS; i++)
-        if (status[i] == -1) work(i);  // (a thread that could not be had: this one does its slice)
+    });
     for (int i = 0; i < PINNED_READERS; i++)
         if (status[i] != ORCD_OK) return status[i];
     return ORCD_OK;

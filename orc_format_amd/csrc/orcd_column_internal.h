@@ -42,11 +42,21 @@ extern "C" int orcd_internal_inflate_list(int codec, const orcd_internal_host_ch
                                           size_t pitch, uint32_t *sizes);
 
 // Helper threads -- the readers and copiers of a stripe's bytes, the host's decompression threads --
-// come out of one budget for the whole process (orcd_helper_threads): an operation asks for as many
-// as it could use beside the calling thread, gets what is left of the budget (possibly none: the
-// caller then does the work alone), and gives them back when it is done.
-extern "C" int orcd_internal_helpers_lease(int want);
-extern "C" void orcd_internal_helpers_release(int n);
+// are one pool for the whole process, as many as its budget (orcd_helper_threads).
+// fn(arg, 0) on the calling thread and fn(arg, slot) -- slot 1 .. max_helpers, each at most once --
+// on as many of the process's helper threads as are free to join while the caller is at it; returns
+// when all that joined are back.  fn takes pieces of work off a counter of its own.
+extern "C" void orcd_internal_parallel_run(int max_helpers, void (*fn)(void *, int), void *arg);
+// the CPUs the helper threads keep to (the first call decides)
+extern "C" void orcd_internal_pool_bind(const void *cpu_set, size_t cpu_set_bytes);
+#ifdef __cplusplus
+template <class F>
+inline void orcd_parallel(int max_helpers, F &&f) {
+    auto *pf = &f;
+    orcd_internal_parallel_run(
+        max_helpers, [](void *a, int slot) { (*static_cast<decltype(pf)>(a))(slot); }, (void *)pf);
+}
+#endif
 // The CPUs of the NUMA node device memory at PCI address `pci_bus_id` is attached to, as a
 // cpu_set_t the helpers of that device's contexts bind themselves to; false when the system does
 // not say (one node, no sysfs entry) or ORCD_NUMA_BIND=0.

@@ -196,7 +196,7 @@ print(b.value, u.value, p.value, int(all(g == got[0] for g in got)))
 def test_helper_threads_stay_within_the_process_budget(tmp_path, env, want_budget):
     """Six threads decompress a zlib file's chunks at once (every chunk list would take up to 16
     threads of its own): the helpers at work never exceed the budget -- the one number an 8-rank
-    node sets per process -- and nothing is left leased afterwards."""
+    node sets per process -- and none is left at work afterwards."""
     import subprocess
     import sys
     pa = pytest.importorskip("pyarrow")
