@@ -31,6 +31,10 @@ WORKLOADS = {
                   "RLE v2 Delta, 10-bit deltas, runs of 512, monotonic int64, seed 43"),
     "delta_w16": ("delta_monotonic", {"width": 16}, True,
                   "RLE v2 Delta, 16-bit deltas, runs of 512, monotonic int64, seed 43"),
+    "delta_w24": ("delta_monotonic", {"width": 24}, True,
+                  "RLE v2 Delta, 24-bit deltas, runs of 512, monotonic int64, seed 43"),
+    "delta_w32": ("delta_monotonic", {"width": 32}, True,
+                  "RLE v2 Delta, 32-bit deltas, runs of 512, monotonic int64, seed 43"),
     "mixed_short_runs": ("mixed_short_runs", {}, False,
                          "RLE v2 mix of ShortRepeat (3..10 copies) and Direct width 4 runs of 1..64 "
                          "values, unsigned, seed 44: every 512-value window holds about 25 runs"),

@@ -90,7 +90,7 @@ def delta_monotonic(n_runs, width=10, seed=43, runs_per_entry=20, device="cuda",
     run_bytes = 2 + 6 + 2 + payload
     stream = torch.empty((n_runs, run_bytes), dtype=torch.uint8, device=device)
     values = torch.empty((n_runs, 512), dtype=torch.int64, device=device)
-    code = {10: 9, 16: 15}[width]
+    code = {10: 9, 16: 15, 24: 23, 32: 27}[width]  # (the 5-bit width code of the ORC v1 table)
     stream[:, 0] = 0xC0 | (code << 1) | 1
     stream[:, 1] = 0xFF
     base = t0

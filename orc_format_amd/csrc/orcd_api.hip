@@ -771,7 +771,10 @@ int attempt_planned(orcd_ctx *c, const uint8_t *d_stream, size_t len, size_t num
     // window's bytes take to arrive anyway: measured faster up to about 800 stream bytes per
     // window (10-bit deltas: 1.69 against 1.74 ms), slower above (16-bit: 1.83 against 1.79).
     // Segments of unequal run counts (stride_vals) are only for the first.
-    const bool dense = len / n_win <= SELFPLAN_MAX_BYTES_PER_WINDOW;
+    // (a stream too long for the last-level cache: the one launch loads it with the nontemporal
+    // hint, which the separate expansion cannot use, and then wins at every width -- 16-bit deltas
+    // 1.68 against 1.79 ms, 24-bit 1.85 against 1.97, 32-bit 2.02 against 2.11 per 10^9 values)
+    const bool dense = len / n_win <= SELFPLAN_MAX_BYTES_PER_WINDOW || len > SELFPLAN_STREAMING_BYTES;
     bool selfplan = (stride_vals || dense || !even) && !(((uintptr_t)d_out) & 15) &&
                     rlev2_selfplan_shape((uint32_t)n_entries, (uint32_t)n_win, stride_vals);
     // (a context whose last such column was one the single launch gave up on and the separate pass

@@ -129,6 +129,9 @@ hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t le
 // The counting pass for streams of at most COOP_MAX_SEGMENTS segments: a wavefront per segment
 // (see rlev2_coop_count_kernel); same results in `t`, same staging.
 constexpr uint32_t COOP_MAX_SEGMENTS = 16384;
+// A stream longer than this does not stay in the 256 MB last-level cache between its loads:
+// rlev2_selfplan_values_kernel loads it with the nontemporal hint.
+constexpr uint64_t SELFPLAN_STREAMING_BYTES = 512ull << 20;
 hipError_t launch_rlev2_coop_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                                    const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                                    int is_signed, const SegTable &t, uint64_t *staged, uint32_t staged_cap);

@@ -2971,7 +2971,7 @@ hipError_t launch_rlev2_selfplan_values(hipStream_t st, const uint8_t *stream, u
     // nontemporal hint: 1.67 -> 1.62 ms on 10^9 values of 10-bit deltas (1.27 GB), while the 130 MB
     // of 10^8 timestamps took 0.206 instead of 0.185 ms with it.  (The hint costs the strided and
     // the planned kernel 2-3 % at every size: their neighbouring windows share more lines.)
-    const uint32_t stream_once = len > (512ull << 20);
+    const uint32_t stream_once = len > SELFPLAN_STREAMING_BYTES;
     rlev2_selfplan_values_kernel<<<blocks, VAL_WAVES * 64, 0, st>>>(stream, len, (const SegPlan *)seg_table, n_seg, n_win,
                                                                    magic, num_values, is_signed, out, flag, stream_once);
     return hipGetLastError();
