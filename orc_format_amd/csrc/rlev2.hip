@@ -2071,11 +2071,12 @@ __device__ __forceinline__ uint64_t decode_run_batch(const W &wv, const uint64_t
 // the sums.  MODE_OFFSETS: group_sums[g] holds the sum of all values before group g, and out[i]
 // receives the sum of the values before i.
 // SHORT: the variant for columns of short runs (many runs per window), compiled for fewer
-// wavefronts per SIMD and more registers each; only there does a batch of runs without running
+// wavefronts per SIMD and more registers each (six: 4 / 5 / 6 / 7 / 8 measured 1.15 / 1.15 / 1.09 /
+// 1.14 / 1.32 ms on 5 * 10^8 values in 2.5 * 10^7 runs); only there does a batch of runs without running
 // sums take the lane-per-eight-values path (decode_short_batch), whose registers the variant for
 // long runs, which wants all eight wavefronts to saturate HBM, cannot afford.
 template <int MODE, bool SHORT>
-__global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 5 : 8) void rlev2_values_kernel(
+__global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 6 : 8) void rlev2_values_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ runs,
     const uint32_t *__restrict__ group_first, const RunEntry *__restrict__ group_run,
     uint32_t n_groups, uint32_t n_runs, uint64_t num_values, int is_signed,
