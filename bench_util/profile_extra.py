@@ -64,6 +64,31 @@ def patched_base(ctx):
           (n, stream.numel(), sorted(size)[:3], dt * 1e3, n * 8 / dt / 1e9), flush=True)
 
 
+def offgrid(ctx):
+    """The headline column (Direct, width 17, runs of 512) behind one run of 300 values: no run
+    starts on a window boundary any more and every window of 512 values holds parts of two runs --
+    what a file's column looks like after its first short run.  Entry points every 20 runs."""
+    import rle_encode as enc
+    from bench_util import synth
+    n_runs = int(os.environ.get("OFFGRID_RUNS", str(2 * 10**8 // 512)))
+    stream, entries, values = synth.direct_w17(n_runs, seed=42, device="cuda")
+    rng = np.random.default_rng(2)
+    head_vals = rng.integers(-(1 << 16), 1 << 16, size=300, dtype=np.int64)
+    head = np.frombuffer(enc.direct(head_vals, 17, True), dtype=np.uint8).copy()
+    stream = torch.cat([torch.from_numpy(head).cuda(), stream])
+    expect = torch.cat([torch.from_numpy(head_vals).cuda(), values])
+    entries = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), entries[1:] + head.size,
+                         ]) if entries.numel() > 1 else torch.zeros(1, dtype=torch.int64, device="cuda")
+    n = expect.numel()
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    dt = timed(ctx, lambda: ctx.rlev2_device(stream.data_ptr(), stream.numel(), n, True, out.data_ptr(),
+                                             entries.data_ptr(), entries.numel()))
+    assert torch.equal(out, expect)
+    print("offgrid: %d values, %d stream bytes, %.3f ms, %.0f GB/s decoded, path %d, kernel %s, phases %s" %
+          (n, stream.numel(), dt * 1e3, n * 8 / dt / 1e9, ctx.last_path(), ctx.last_value_kernel(),
+           [round(ctx.phase_ms(p), 4) for p in (1, 2, 3)]), flush=True)
+
+
 def dictionary(ctx):
     """10^8 indices into a dictionary of 1000 entries of 4..28 bytes: offsets + gathered bytes.
     (DICT_ENTRIES / DICT_MAX_LEN in the environment: another dictionary, e.g. one too large for LDS.)"""
@@ -214,5 +239,5 @@ def inflate(ctx):
 
 
 if __name__ == "__main__":
-    {"patched_base": patched_base, "dictionary": dictionary, "byte_rle": byte_rle, "scatter": scatter,
+    {"patched_base": patched_base, "offgrid": offgrid, "dictionary": dictionary, "byte_rle": byte_rle, "scatter": scatter,
      "rlev1": rlev1, "inflate": inflate}[sys.argv[1]](Context(0))

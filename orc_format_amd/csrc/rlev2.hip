@@ -1467,6 +1467,19 @@ __device__ __forceinline__ void decode_single_run(const W &wv, uint64_t desc, ui
                              ((run_out & 1) == 0);
     if (patch_ahead) stage_patches(wv, desc, aux);
     uint64_t carry = 0;  // Delta: sum of the run's packed deltas before the current step
+    // The packed fields of all the run's wanted values are staged once (a run fits the slice): a
+    // run that starts inside a window lies in two, and a staging per window was a second trip to
+    // memory for bytes that follow right behind the first's.
+    uint32_t bit0 = 0;  // bit position in LDS of packed field 0 of the run (modulo 2^32)
+    const bool two_windows = ((run_end - 1) >> WINDOW_SHIFT) != (run_out >> WINDOW_SHIFT);
+    if (packed_kind && two_windows) {
+        uint64_t b0, b1;
+        payload_range(kind, w, 0u, (uint32_t)(run_end - run_out), b0, b1);
+        if (b1 > b0) {
+            const uint64_t origin = stage_bytes<W::SHORT>(wv, desc_payload(desc) + b0, desc_payload(desc) + b1);
+            bit0 = (uint32_t)((desc_payload(desc) - origin) << 3);
+        }
+    }
     for (uint64_t wbase = (run_out >> WINDOW_SHIFT) << WINDOW_SHIFT; wbase < run_end; wbase += WINDOW) {
         // active values of this window, relative to its start
         const uint32_t lo_rel = wbase > run_out ? 0u : (uint32_t)(run_out - wbase);
@@ -1474,8 +1487,7 @@ __device__ __forceinline__ void decode_single_run(const W &wv, uint64_t desc, ui
         const bool full = lo_rel == 0 && hi_rel == WINDOW && wv.out_aligned;
         // index in the run of the window's first value (negative before the run)
         const int32_t win_idx = (int32_t)(int64_t)(wbase - run_out);
-        uint32_t bit0 = 0;  // bit position in LDS of packed field 0 of the run (modulo 2^32)
-        if (packed_kind) {
+        if (packed_kind && !two_windows) {
             uint64_t b0, b1;
             payload_range(kind, w, (uint32_t)(win_idx + (int32_t)lo_rel),
                           (uint32_t)(win_idx + (int32_t)hi_rel), b0, b1);
