@@ -432,7 +432,7 @@ __device__ __forceinline__ uint32_t stream_byte(const uint8_t *s, uint64_t src, 
 // and the next one, i.e. 16 values, so that each store instruction writes 1 KiB of consecutive
 // values.  The runs that overlap the tile are loaded once, one per lane, the stream bytes between
 // the first run's source and the last one's are staged in LDS with one or two 16-byte loads per
-// lane, and every lane then finds the runs of its bytes with register shuffles and its bytes in
+// lane (loads that write LDS themselves), and every lane then finds the runs of its bytes with register shuffles and its bytes in
 // LDS (a tile overlapped by more than 64 runs falls back to per-lane walks of the run table).
 // out_bytes: one byte per value; out_bitmap: the same bits least-significant-first; *set_bits:
 // the number of ones.
@@ -558,13 +558,12 @@ __global__ __launch_bounds__(256) void bool_expand_kernel(
                 const uint4 *src16 = (const uint4 *)(sb - skew);
                 const uint32_t n16 = (uint32_t)((span + skew + 15) >> 4);  // <= BOOL_SLICE / 16 + 1
                 constexpr uint32_t ROUNDS = (BOOL_SLICE / 16 + 1 + 63) / 64;
-                uint4 c[ROUNDS];
 #pragma unroll
                 for (uint32_t r = 0; r < ROUNDS; r++)
-                    if (lane + 64 * r < n16) c[r] = src16[lane + 64 * r];
-#pragma unroll
-                for (uint32_t r = 0; r < ROUNDS; r++)
-                    if (lane + 64 * r < n16) ((uint4 *)slice)[lane + 64 * r] = c[r];
+                    if (lane + 64 * r < n16)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src16 + lane + 64 * r),
+                                                         (__attribute__((address_space(3))) void *)(slice + 1024 * r), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 // the last offset a look-up may use: every byte that is wanted lies inside a run,
