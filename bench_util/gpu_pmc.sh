@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of one workload's kernels: bash bench_util/gpu_pmc.sh <tag> <workload> (env passes through)
+# SQ counters of one workload's kernels: bash bench_util/gpu_pmc.sh <tag> <workload | extra:case> (env passes through)
 set -e -o pipefail
 TAG=$1; WL=$2
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -7,7 +7,11 @@ O=$R/gpurun_out/pmc_${TAG}
 rm -rf $O && mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-SHORT="bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --headline-only"
+if [ "${WL#extra:}" != "$WL" ]; then
+  SHORT="bench_util/profile_extra.py ${WL#extra:}"
+else
+  SHORT="bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --headline-only"
+fi
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/a -- python3 $SHORT > $O/a.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_INSTS_SMEM --output-format csv -d $O/b -- python3 $SHORT > $O/b.log 2>&1
 python3 - $O <<'PY'

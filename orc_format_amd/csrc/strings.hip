@@ -658,7 +658,19 @@ __global__ __launch_bounds__(DG_THREADS, SHORT ? 8 : 6) void dictionary_gather_k
                 if (b0 >= lead && b1 <= end) {
                     *(uint4 *)(aligned + b0) = *(const uint4 *)(image8 + c * 16);
                 } else {
-                    for (uint32_t b = b0 < lead ? lead : b0; b < (b1 < end ? b1 : end); b++) aligned[b] = image8[b - wb];
+                    // a piece shared with a neighbouring wavefront: its bytes [p, q) in at most
+                    // seven naturally aligned stores (1, 2, 4 bytes up to an 8-byte boundary, 8, then
+                    // 4, 2, 1), not a loop of up to fifteen single bytes
+                    uint32_t p = b0 < lead ? lead : b0;
+                    const uint32_t q = b1 < end ? b1 : end;
+                    const uint8_t *im = image8 - wb;
+                    if ((p & 1) && p + 1 <= q) { aligned[p] = im[p]; p += 1; }
+                    if ((p & 2) && p + 2 <= q) { *(uint16_t *)(aligned + p) = *(const uint16_t *)(im + p); p += 2; }
+                    if ((p & 4) && p + 4 <= q) { *(uint32_t *)(aligned + p) = *(const uint32_t *)(im + p); p += 4; }
+                    if (p + 8 <= q) { *(uint64_t *)(aligned + p) = *(const uint64_t *)(im + p); p += 8; }
+                    if (p + 4 <= q) { *(uint32_t *)(aligned + p) = *(const uint32_t *)(im + p); p += 4; }
+                    if (p + 2 <= q) { *(uint16_t *)(aligned + p) = *(const uint16_t *)(im + p); p += 2; }
+                    if (p + 1 <= q) aligned[p] = im[p];
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
