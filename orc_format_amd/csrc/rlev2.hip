@@ -173,6 +173,41 @@ __device__ __forceinline__ uint32_t parse_run(const Window16 &w, const uint8_t *
     return SEG_OK;
 }
 
+// The size in bytes of the run whose header the window starts with, by arithmetic alone: every
+// kind worked out side by side and picked by selects, for lanes that look at byte offsets most of
+// which are no headers at all (a branch per kind makes such a wavefront run all four, the loops
+// over a Delta header's varints included).  0: not a header, not one whose run fits `room` bytes,
+// or a Delta header whose two varints are not inside the window.  Only a hint: whoever acts on it
+// checks with parse_run, which alone decides what is a run and what is out of spec.
+__device__ __forceinline__ uint32_t quick_run_size(const Window16 &w, uint64_t room) {
+    const uint32_t h = (uint32_t)w.lo;
+    const uint32_t kind = (h >> 6) & 3u, code = (h >> 1) & 31u;
+    const uint32_t wd = width_from_code(code);
+    const uint32_t len9 = (((h & 1u) << 8) | ((h >> 8) & 0xFFu)) + 1u;
+    const uint32_t packed = (wd * len9 + 7u) >> 3;
+    const uint32_t size_sr = 2u + ((h >> 3) & 7u);
+    const uint32_t size_direct = 2u + packed;
+    // Delta: the continuation bits of bytes 2 .. 15 say how long the two varints are
+    auto msb4 = [](uint32_t v) { return (((v >> 7) & 0x01010101u) * 0x01020408u) >> 24; };  // the top bits of 4 bytes as 4 bits
+    const uint64_t x = (w.lo >> 16) | (w.hi << 48);  // bytes 2 .. 9
+    const uint32_t c = msb4((uint32_t)x) | (msb4((uint32_t)(x >> 32)) << 4) | (msb4((uint32_t)(w.hi >> 16)) << 8) |
+                       ((msb4((uint32_t)(w.hi >> 48)) & 3u) << 12);  // 14 bits
+    const uint32_t l1 = (uint32_t)__builtin_ctz(~c) + 1u;  // at most 15
+    const uint32_t l2 = (uint32_t)__builtin_ctz(~(c >> l1)) + 1u;
+    const bool delta_ok = l1 <= 10u && l2 <= 10u && l1 + l2 <= 14u && !(code != 0 && len9 < 2u);
+    const uint32_t size_delta = 2u + l1 + l2 + (len9 < 2u ? 0u : ((code ? wd : 0u) * (len9 - 2u) + 7u) >> 3);
+    // PatchedBase
+    const uint32_t h2 = (h >> 16) & 0xFFu, h3 = h >> 24;
+    const uint32_t pw = width_from_code(h2 & 31u), gw = (h3 >> 5) + 1u, pll = h3 & 31u;
+    const bool pb_ok = pll != 0 && pw + gw <= 64u;
+    const uint32_t size_pb = 5u + (h2 >> 5) + packed + ((closest_fixed_bits(pw + gw) * pll + 7u) >> 3);
+    const uint32_t size = kind == KIND_SHORT_REPEAT ? size_sr
+                          : kind == KIND_DIRECT     ? size_direct
+                          : kind == KIND_DELTA      ? (delta_ok ? size_delta : 0u)
+                                                    : (pb_ok ? size_pb : 0u);
+    return size <= room ? size : 0u;
+}
+
 // A lane's private stretch of stream bytes in LDS: where runs are short, the next few headers lie
 // within the bytes fetched for the current one, and parsing them from here saves the memory round
 // trip each would otherwise cost.
@@ -395,21 +430,31 @@ __global__ __launch_bounds__(SEG_BLOCK) void rlev2_scan_kernel(
 // header in about half a microsecond, and a segment of thousands of short runs -- or a whole
 // stream that came without entry points -- is thousands of those in a row.  Here the lanes parse,
 // at once, the 64 byte offsets that follow the current header (or, after a run of 64 bytes and
-// more, 64 guesses at that run's stride); the first offset is a real header, and a scalar loop
-// hops from it along the true chain at a readlane per run.  The headers found collect in an LDS
-// ring and are parsed in full 64 at a time, which is also where their descriptors are staged.
+// more, 64 guesses at that run's stride); the first offset is a real header, and the chain that
+// starts there is picked out of the 64 guesses by pointer doubling (five rounds of lane
+// permutes; a scalar loop that hops along it costs a readlane and a branch per run).  Only the
+// offsets on the chain are parsed in full -- the others are sized by quick_run_size alone -- and
+// their descriptors collect in an LDS ring and leave for the staging area 64 at a time.
+// (A stripe of a file, 450 segments of 2 100 short runs each: 313 -> 140 microseconds, of which
+// the bytes in LDS 105, the descriptors kept instead of a second parse and the sizing by
+// arithmetic the rest.)
+// A segment whose bytes fit the wavefront's LDS slice is copied there first (loads that write LDS
+// themselves) and every window of 16 header bytes is then put together from LDS reads: a round
+// of 64 offsets no longer waits for memory.  Longer segments are parsed from memory as before.
+// One wavefront per workgroup; dynamic LDS: COOP_RING * 8 + slice_bytes + 32.
 // Writes t.seg_count only; rlev2_publish_kernel turns that into the scan's inputs.
 constexpr uint32_t COOP_RING = 128;
 constexpr uint32_t COUNT_SLICE_BYTES = 48 << 10;  // stream bytes a wavefront of rlev2_count_staged_kernel holds
 
-__global__ __launch_bounds__(256) void rlev2_coop_count_kernel(
+__global__ __launch_bounds__(64) void rlev2_coop_count_kernel(
     const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
     const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
-    uint64_t *__restrict__ staged, uint32_t staged_cap) {
-    __shared__ uint64_t ring_all[4][COOP_RING];
-    uint64_t *ring = ring_all[threadIdx.x >> 6];
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint64_t *__restrict__ staged, uint32_t staged_cap, uint32_t slice_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t coop_dyn[];
+    uint64_t *ring = (uint64_t *)coop_dyn;
+    uint8_t *slice = coop_dyn + COOP_RING * sizeof(uint64_t);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t seg = blockIdx.x;
     if (seg >= n_seg) return;  // whole wavefront
     // the segment's bounds, as rlev2_scan_kernel takes them
     uint64_t pos = (entries && (seg > 0 || seg_ends)) ? entries[seg] : 0;
@@ -424,89 +469,144 @@ __global__ __launch_bounds__(256) void rlev2_coop_count_kernel(
     uint64_t n_vals = 0, last_size = 0;
     if (end > len || end < pos) status = SEG_MISALIGNED;
     uint64_t *mine = staged ? staged + (uint64_t)seg * staged_cap : nullptr;
-    for (;;) {
-        // ---- find headers until 64 are waiting or the segment ends -----------------------
-        while (status == SEG_OK && pos < end && ring_n < 64) {
-            const bool strided = last_size >= 64;
-            const uint64_t stride = strided ? last_size : 1;
-            const uint64_t p = pos + (uint64_t)lane * stride;
-            const bool inb = p < end;
-            uint32_t st = SEG_OK;
-            uint64_t size = 0;
-            if (inb) {
-                ParsedRun r;
-                st = parse_run(load_window(s, limit, p), s, limit, p, is_signed, r);
-                size = r.run_end - p;
-            }
-            const uint32_t st0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
-            if (st0 != SEG_OK) {  // the header at pos is a real one: the walk stops here
-                status = st0;
-                break;
-            }
-            uint32_t accepted;
-            if (strided) {
-                // offset k * stride is a header if every run before it was `stride` long
-                const uint64_t same = __ballot(inb && st == SEG_OK && size == stride);
-                const uint32_t lead = same == ~0ull ? 64u : (uint32_t)__ffsll((unsigned long long)~same) - 1u;
-                if (lead == 0) {  // the run at pos has another size: it alone is taken
-                    accepted = 1;
-                    last_size = readfirstlane64(size);
-                    if (lane == 0) ring[ring_n] = p;
-                    pos += last_size;
-                } else {
-                    accepted = lead;
-                    if (lane < lead) ring[ring_n + lane] = p;
-                    pos += (uint64_t)lead * stride;
-                }
-            } else {
-                uint64_t chain = 0;
-                uint32_t cur = 0;
-                while (cur < 64) {
-                    if (pos + cur >= end) break;
-                    if (readlane32(st, (int)cur) != SEG_OK) break;  // a real header that does not parse: reported when it is at pos
-                    chain |= 1ull << cur;
-                    last_size = readlane64(size, (int)cur);
-                    if (last_size >= 64 - cur) {  // the next header lies past these 64 offsets
-                        pos += cur + last_size;
-                        cur = 0xFFFFFFFFu;
-                        break;
-                    }
-                    cur += (uint32_t)last_size;
-                }
-                if (cur != 0xFFFFFFFFu) pos += cur;  // stopped inside: at the segment's end or at a bad header
-                accepted = (uint32_t)__popcll((unsigned long long)chain);
-                if ((chain >> lane) & 1) ring[ring_n + (uint32_t)__popcll((unsigned long long)(chain & ((1ull << lane) - 1)))] = p;
-            }
-            ring_n += accepted;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+    // the segment's bytes and the 20 after them (a header at the segment's last byte is looked at
+    // as 16 bytes + 4 of alignment), as far as the stream goes
+    const uint64_t lo = pos;
+    const uint32_t skew = (uint32_t)((uintptr_t)(s + lo) & 15);
+    const bool in_lds = status == SEG_OK && end > lo && end - lo + skew + 24 <= slice_bytes;
+    if (in_lds) {
+        const uintptr_t a0 = (uintptr_t)(s + lo) - skew, stop = (uintptr_t)(s + len);
+        const uint32_t n16 = (uint32_t)((end - lo + skew + 24 + 15) >> 4);  // <= slice_bytes / 16 + 1 (the slice has 32 bytes to spare)
+        for (uint32_t c0 = 0; c0 < n16; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            if (c < n16 && a0 + 16 * (uintptr_t)c < stop)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a0 + 16 * (uintptr_t)c),
+                                                 (__attribute__((address_space(3))) void *)(slice + 16 * c0), 16, 0, 0);
         }
-        if (ring_n == 0) break;
-        // ---- the next (up to) 64 headers in full ------------------------------------------
-        const uint32_t take = ring_n < 64 ? ring_n : 64;
-        uint32_t rlen = 0;
-        if (lane < take) {
-            const uint64_t p = ring[lane];
-            ParsedRun r;
-            (void)parse_run(load_window(s, limit, p), s, limit, p, is_signed, r);  // parsed fine a moment ago
-            rlen = r.len;
-            if (mine && n_runs + lane < staged_cap)
-                mine[n_runs + lane] = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes);
-        }
-        uint32_t sum = rlen;
-        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-        n_vals += sum;
-        last_len = readlane32(rlen, (int)take - 1);
-        n_runs += take;
-        const uint32_t rest = ring_n - take;  // at most 63
-        const uint64_t moved = lane < rest ? ring[take + lane] : 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < rest) ring[lane] = moved;
-        ring_n = rest;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    // (two copies of the walk, so that the one over LDS carries no test of where its bytes are)
+    auto walk = [&](auto from_lds) {
+        constexpr bool IN_LDS = decltype(from_lds)::value;
+        const uint32_t *words = (const uint32_t *)slice;
+        auto window_at = [&](uint64_t p) -> Window16 {
+            if (!IN_LDS) return load_window(s, limit, p);
+            // (bytes past the stream's end: whatever the slice holds there; a run that needs them
+            // is found truncated by its end, as with load_window)
+            const uint32_t o = (uint32_t)(p - lo) + skew, k = o >> 2, sh = o & 3u;
+            const uint32_t w0 = words[k], w1 = words[k + 1], w2 = words[k + 2], w3 = words[k + 3], w4 = words[k + 4];
+            Window16 w;
+            w.lo = ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32) | __builtin_amdgcn_alignbyte(w1, w0, sh);
+            w.hi = ((uint64_t)__builtin_amdgcn_alignbyte(w4, w3, sh) << 32) | __builtin_amdgcn_alignbyte(w3, w2, sh);
+            return w;
+        };
+        for (;;) {
+            // ---- find headers until 64 are waiting or the segment ends -------------------
+            while (status == SEG_OK && pos < end && ring_n < 64) {
+                const bool strided = last_size >= 64;
+                const uint64_t stride = strided ? last_size : 1;
+                const uint64_t p = pos + (uint64_t)lane * stride;
+                const bool inb = p < end;
+                Window16 w = {0, 0};
+                if (inb) w = window_at(p);
+                uint32_t st = SEG_OK;
+                uint64_t size = 0, desc = 0;
+                auto parse = [&]() {
+                    ParsedRun r;
+                    st = parse_run(w, s, limit, p, is_signed, r);
+                    size = r.run_end - p;
+                    desc = make_desc(r.payload_off, r.kind, r.width, r.len, r.delta_neg, r.header_bytes);
+                };
+                uint32_t accepted;
+                if (strided) {
+                    if (inb) parse();
+                    const uint32_t st0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
+                    if (st0 != SEG_OK) {  // the header at pos is a real one: the walk stops here
+                        status = st0;
+                        break;
+                    }
+                    // offset k * stride is a header if every run before it was `stride` long
+                    const uint64_t same = __ballot(inb && st == SEG_OK && size == stride);
+                    const uint32_t lead = same == ~0ull ? 64u : (uint32_t)__ffsll((unsigned long long)~same) - 1u;
+                    if (lead == 0) {  // the run at pos has another size: it alone is taken
+                        accepted = 1;
+                        last_size = readfirstlane64(size);
+                        if (lane == 0) ring[ring_n] = desc;
+                        pos += last_size;
+                    } else {
+                        accepted = lead;
+                        if (lane < lead) ring[ring_n + lane] = desc;
+                        pos += (uint64_t)lead * stride;
+                    }
+                } else {
+                    // Every offset's guess at where the next header lies, then the chain from
+                    // offset 0 (the one real header) by pointer doubling: after k steps lane i
+                    // holds the first 2^k offsets of the chain that starts at i.  A run takes two
+                    // bytes at least, so 32 links cover the 64 offsets.
+                    const uint32_t q = inb ? quick_run_size(w, limit - p) : 0u;
+                    uint32_t jump = (q != 0 && lane + q < 64) ? lane + q : lane;  // (itself: the chain stops here)
+                    uint64_t links = q != 0 ? 1ull << lane : 0;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        links |= shfl64(links, (int)jump);
+                        jump = __shfl(jump, (int)jump);
+                    }
+                    uint64_t chain = readfirstlane64(links);
+                    if (chain == 0) chain = 1;  // no guess for the header at pos: parse_run says what it is
+                    // the offsets on the chain are parsed in full: nothing is taken on the guess alone
+                    if ((chain >> lane) & 1) parse();
+                    const uint64_t off = __ballot(((chain >> lane) & 1) && (st != SEG_OK || size != q));
+                    if (off) {
+                        // the chain is cut at the first offset whose run is not what was guessed: a
+                        // run of another size is taken (it is the real one), whatever does not
+                        // parse is reported once it is the header at pos
+                        const uint32_t f = (uint32_t)__ffsll((unsigned long long)off) - 1u;
+                        const uint32_t st_f = readlane32(st, (int)f);
+                        chain &= (1ull << f) - 1;
+                        if (st_f == SEG_OK) chain |= 1ull << f;
+                        if (chain == 0) {
+                            status = st_f;
+                            break;
+                        }
+                    }
+                    const uint32_t last = 63u - (uint32_t)__builtin_clzll((unsigned long long)chain);
+                    last_size = readlane64(size, (int)last);
+                    pos += last + last_size;  // where the next header is, inside these 64 offsets or past them
+                    accepted = (uint32_t)__popcll((unsigned long long)chain);
+                    if ((chain >> lane) & 1) ring[ring_n + (uint32_t)__popcll((unsigned long long)(chain & ((1ull << lane) - 1)))] = desc;
+                }
+                ring_n += accepted;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (ring_n == 0) break;
+            // ---- the next (up to) 64 descriptors leave the ring ------------------------------
+            const uint32_t take = ring_n < 64 ? ring_n : 64;
+            uint32_t rlen = 0;
+            if (lane < take) {
+                const uint64_t d = ring[lane];
+                rlen = desc_len(d);
+                if (mine && n_runs + lane < staged_cap) mine[n_runs + lane] = d;
+            }
+            uint32_t sum = rlen;
+            for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+            n_vals += sum;
+            last_len = readlane32(rlen, (int)take - 1);
+            n_runs += take;
+            const uint32_t rest = ring_n - take;  // at most 63
+            const uint64_t moved = lane < rest ? ring[take + lane] : 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) ring[lane] = moved;
+            ring_n = rest;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    if (in_lds) walk(std::true_type{});
+    else walk(std::false_type{});
     if (status == SEG_OK && pos != end && !last_seg) status = SEG_MISALIGNED;
     if (lane == 0) {
         SegCount c;
@@ -3050,8 +3150,12 @@ hipError_t launch_rlev2_count(hipStream_t st, const uint8_t *stream, uint64_t le
 hipError_t launch_rlev2_coop_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                                    const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                                    int is_signed, const SegTable &t, uint64_t *staged, uint32_t staged_cap) {
-    rlev2_coop_count_kernel<<<(n_seg + 3) / 4, 256, 0, st>>>(stream, len, entries, seg_ends, n_seg, is_signed, t,
-                                                             staged, staged_cap);
+    // the LDS slice: room for a segment twice the average (whatever is longer is parsed from memory),
+    // and no more than lets five wavefronts share a compute unit
+    const uint64_t want = (2 * (len / n_seg) + 64 + 4095) / 4096 * 4096;
+    const uint32_t slice_bytes = (uint32_t)(want < 8192 ? 8192 : want > 32768 ? 32768 : want);
+    rlev2_coop_count_kernel<<<n_seg, 64, COOP_RING * sizeof(uint64_t) + slice_bytes + 32, st>>>(
+        stream, len, entries, seg_ends, n_seg, is_signed, t, staged, staged_cap, slice_bytes);
     rlev2_publish_kernel<<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(n_seg, t);
     return hipGetLastError();
 }
