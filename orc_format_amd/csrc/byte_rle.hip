@@ -21,6 +21,12 @@ size_t byte_rle_window_slots(uint64_t total_bytes) {
     return (size_t)((total_bytes + BR_WINDOW - 1) >> BR_WINDOW_SHIFT) + 1;
 }
 
+__device__ __forceinline__ uint64_t readfirst_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // COUNT pass: runs and bytes per segment.  EMIT pass: the run table, a sentinel run one past the
 // end, and win_first[w] = index of the first run that starts inside or after window w.  A run is
 // at most 130 bytes, so it can span at most one whole window in which nothing starts; the lane
@@ -113,6 +119,110 @@ __global__ __launch_bounds__(SEG_BLOCK) void byte_rle_scan_kernel(
     }
 }
 
+// COUNT for streams of few segments (a stripe's PRESENT stream with an entry point per row group):
+// the lane-per-segment walk above waits for memory at every control byte, about a microsecond a
+// hop, with a handful of wavefronts on the whole chip -- a hundred hops are a hundred
+// microseconds whatever the stream's size.  Here a wavefront copies the bytes that `group`
+// neighbouring segments span into LDS first (loads that write LDS themselves, every line fetched
+// once) and `group` of its lanes walk a segment each out of LDS, a hop an LDS read.  A span that
+// does not fit the slice is walked from memory as above.
+// Writes t.seg_count only; byte_rle_publish_kernel turns that into the scan's inputs.
+// One wavefront per workgroup; dynamic LDS: slice_bytes + 32.
+__global__ __launch_bounds__(64) void byte_rle_count_staged_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ entries,
+    const uint64_t *__restrict__ seg_ends, uint32_t n_seg, SegTable t, uint64_t *__restrict__ staged,
+    uint32_t staged_cap, uint32_t group, uint32_t slice_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t br_dyn[];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t first64 = (uint64_t)blockIdx.x * group;
+    if (first64 >= n_seg) return;  // whole wavefront
+    const uint32_t seg = (uint32_t)first64 + lane;
+    const bool valid = lane < group && seg < n_seg;
+    // a segment's bounds: as in byte_rle_scan_kernel
+    uint64_t pos = (valid && entries && (seg > 0 || seg_ends)) ? entries[seg] : 0;
+    uint64_t end = (valid && entries && seg + 1 < n_seg) ? entries[seg + 1] : len;
+    if (valid && seg_ends) end = seg_ends[seg];
+    const uint64_t limit = seg_ends ? (end < len ? end : len) : len;
+    const bool last_seg = seg + 1 == n_seg;
+    if (pos > len) pos = len;
+    uint32_t status = SEG_OK;
+    if (end > len || end < pos) status = SEG_MISALIGNED;
+    const bool walking = valid && status == SEG_OK && pos < end;
+    // what the walking lanes span
+    uint64_t lo = walking ? pos : ~0ull, hi = walking ? end : 0;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t ol = ((uint64_t)__shfl_xor((uint32_t)(lo >> 32), d) << 32) | __shfl_xor((uint32_t)lo, d);
+        const uint64_t oh = ((uint64_t)__shfl_xor((uint32_t)(hi >> 32), d) << 32) | __shfl_xor((uint32_t)hi, d);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    lo = readfirst_u64(lo);
+    hi = readfirst_u64(hi);
+    const uint32_t skew = (uint32_t)((uintptr_t)(s + (hi > lo ? lo : 0)) & 15);
+    const bool in_lds = hi > lo && hi - lo + skew <= slice_bytes;
+    if (in_lds) {
+        const uintptr_t a0 = (uintptr_t)(s + lo) - skew;
+        const uint32_t n16 = (uint32_t)((hi - lo + skew + 15) >> 4);  // hi <= len: every chunk starts inside the stream
+        for (uint32_t c0 = 0; c0 < n16; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            if (c < n16)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a0 + 16 * (uintptr_t)c),
+                                                 (__attribute__((address_space(3))) void *)(br_dyn + 16 * c0), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    uint32_t n_runs = 0, last_len = 0;
+    uint64_t n_bytes = 0;
+    uint64_t *mine = staged + (uint64_t)seg * staged_cap;
+    const uint32_t cap_mine = (staged && valid) ? staged_cap : 0;
+    if (walking) {
+        while (status == SEG_OK && pos < end) {
+            const uint32_t c = in_lds ? br_dyn[(uint32_t)(pos - lo) + skew] : s[pos];
+            const bool run = c < 128;
+            const uint32_t n = run ? c + 3 : 256 - c;
+            const uint64_t next = run ? pos + 2 : pos + 1 + n;
+            if (next > limit) {
+                status = SEG_TRUNCATED;
+                break;
+            }
+            if (pos + 1 > PAYLOAD_MASK) {
+                status = SEG_TOO_LONG;
+                break;
+            }
+            if (n_runs < cap_mine) mine[n_runs] = ((pos + 1) | (run ? BR_IS_RUN : 0)) | ((uint64_t)(n - 1) << 40);
+            n_runs++;
+            n_bytes += n;
+            last_len = n;
+            pos = next;
+        }
+        if (status == SEG_OK && pos != end && !last_seg) status = SEG_MISALIGNED;
+    }
+    if (valid) {
+        SegCount c;
+        c.n_runs = n_runs;
+        c.last_len = last_len;
+        c.status = status;
+        c.pad = 0;
+        c.n_vals = n_bytes;
+        t.seg_count[seg] = c;
+    }
+}
+
+// What byte_rle_count_staged_kernel left in t.seg_count, through the workgroup-local scan that the
+// counting kernel proper ends with.
+__global__ __launch_bounds__(SEG_BLOCK) void byte_rle_publish_kernel(uint32_t n_seg, SegTable t) {
+    const uint32_t seg = blockIdx.x * SEG_BLOCK + threadIdx.x;
+    SegCount c;
+    c.n_runs = 0;
+    c.last_len = 0;
+    c.status = SEG_OK;
+    c.n_vals = 0;
+    if (seg < n_seg) c = t.seg_count[seg];
+    seg_publish(t, seg, n_seg, c.n_runs, c.last_len, c.status, c.n_vals);
+}
+
 // EMIT for the segments whose run words the counting pass staged: a group of lanes per segment,
 // one lane per run (a segment with more runs than lanes takes them a group at a time); a run's
 // place in the output follows from a scan of the lengths.
@@ -178,12 +288,6 @@ __global__ __launch_bounds__(256) void byte_rle_emit_staged_kernel(
         before += __shfl(incl, (int)group - 1, (int)group);
         carry_prev = __shfl(n, (int)group - 1, (int)group);
     }
-}
-
-__device__ __forceinline__ uint64_t readfirst_u64(uint64_t v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
 }
 
 __device__ __forceinline__ uint32_t byte_run_len(const ByteRun &r) {
@@ -857,9 +961,27 @@ constexpr uint64_t BR_MAX_BLOCKS = 256 * 16;  // workgroups of the expansion: 16
 // made the larger grids three to six times slower).
 constexpr uint64_t BOOL_MAX_BLOCKS = 256 * 256;
 
+constexpr uint32_t BYTE_RLE_STAGED_MAX_SEGMENTS = 16384;
+constexpr uint32_t BYTE_RLE_SLICE_BYTES = 48 << 10;
+
 hipError_t launch_byte_rle_count(hipStream_t st, const uint8_t *stream, uint64_t len,
                                  const uint64_t *entries, const uint64_t *seg_ends, uint32_t n_seg,
                                  const SegTable &t, uint64_t *staged, uint32_t staged_cap) {
+    // Few segments: what the pass costs is the longest walk, not the stream's bytes -- out of LDS
+    // (see byte_rle_count_staged_kernel), as many segments to a wavefront as fit its slice.  Many:
+    // the lane-per-segment walk already runs at the rate memory delivers the lines it touches.
+    if (n_seg <= BYTE_RLE_STAGED_MAX_SEGMENTS) {
+        const uint64_t avg = len / n_seg;
+        uint32_t group = 1;
+        for (uint32_t g : {64u, 32u, 16u, 8u, 4u, 2u})
+            if (group == 1 && avg * g * 5 / 4 + 256 <= BYTE_RLE_SLICE_BYTES) group = g;
+        const uint64_t want = (avg * group * 5 / 4 + 256 + 4095) / 4096 * 4096;
+        const uint32_t slice_bytes = (uint32_t)(want > BYTE_RLE_SLICE_BYTES ? BYTE_RLE_SLICE_BYTES : want);
+        byte_rle_count_staged_kernel<<<(n_seg + group - 1) / group, 64, slice_bytes + 32, st>>>(
+            stream, len, entries, seg_ends, n_seg, t, staged, staged_cap, group, slice_bytes);
+        byte_rle_publish_kernel<<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(n_seg, t);
+        return hipGetLastError();
+    }
     byte_rle_scan_kernel<false><<<(n_seg + SEG_BLOCK - 1) / SEG_BLOCK, SEG_BLOCK, 0, st>>>(
         stream, len, entries, seg_ends, n_seg, t, nullptr, nullptr, 0, staged, staged_cap, 0);
     return hipGetLastError();
