@@ -2313,6 +2313,146 @@ __global__ __launch_bounds__(VAL_WAVES * 64, SHORT ? 6 : 8) void rlev2_values_ke
 }
 
 // ---------------------------------------------------------------------------------------------
+// MODE_SUMS for tables of long runs, four windows to a wavefront.  A wavefront per window spends
+// its start, a chain of three dependent memory hops (the window's entry, its stream bytes, LDS)
+// and a 64-lane reduction on 400 bytes of stream -- 2.5 * 10^8 string lengths are half a million
+// such wavefronts, 0.23 ms for 0.19 GB.  Here the four entries are fetched by four lanes at once,
+// the bytes of all four windows are asked for before any is looked at (a window of one unsigned
+// Direct run of at most 16-bit fields is at most 64 chunks of 16 bytes: one load per lane), all
+// land in the wavefront's LDS slice side by side, and each window's 512 fields are added up eight
+// to a lane with one 32-bit DPP reduction (512 fields of 16 bits cannot wrap).  A wavefront with a
+// window of any other kind takes its windows one by one as rlev2_values_kernel<MODE_SUMS> does.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t SUMS_WINDOWS = 4;
+constexpr uint32_t SUMS_PITCH_WORDS = 264;  // 64 chunks and the word after, per window
+
+// the runs that start in window g, as rlev2_values_kernel expands them
+template <class W>
+__device__ __forceinline__ void expand_window_runs(const W &wv, const uint64_t *__restrict__ runs, uint32_t n_runs,
+                                                   const RunEntry *__restrict__ group_run, uint32_t g) {
+    const RunEntry *e = group_run + g;  // wave-uniform address
+    const uint64_t desc = readfirstlane64(e->desc);
+    if (desc & DESC_SINGLE) {
+        decode_single_run(wv, desc, readfirstlane64(e->out_off), readfirstlane64(e->base), readfirstlane64(e->aux));
+        return;
+    }
+    const uint64_t own_end = ((uint64_t)g + 1) << WINDOW_SHIFT;
+    uint64_t rb64 = readfirstlane64(e->base), beg = readfirstlane64(e->out_off);
+    if (rb64 > n_runs) rb64 = n_runs;
+    for (uint32_t rb = (uint32_t)rb64; rb < n_runs && beg < own_end; rb += 64) {
+        uint32_t nb;
+        beg = decode_run_batch(wv, runs, rb, n_runs - rb, beg, own_end, nb);
+        if (nb < 64) break;
+    }
+}
+
+static_assert(SUMS_WINDOWS * SUMS_PITCH_WORDS <= STAGE_WORDS, "four windows side by side in a wavefront's slice");
+
+// group_sums[g0 .. g0 + nk) as rlev2_values_kernel<MODE_SUMS> computes them, by one wavefront
+__device__ __attribute__((noinline)) void general_window_sums(
+    const uint8_t *s, uint64_t len, const uint64_t *runs, const RunEntry *group_run, uint32_t n_runs,
+    uint64_t num_values, int is_signed, uint64_t *group_sums, uint32_t *flags, uint32_t *lds, uint32_t *marks,
+    uint32_t g0, uint32_t nk) {
+    const uint32_t lane = threadIdx.x & 63;
+    WaveOf<MODE_SUMS> wv;
+    wv.s = s;
+    wv.lds = lds;
+    wv.marks = marks;
+    wv.patch_tab = nullptr;
+    wv.out = nullptr;
+    wv.num_values = num_values;
+    wv.len = len;
+    wv.lane = (int)lane;
+    wv.is_signed = is_signed;
+    wv.out_aligned = false;
+    wv.saw_patched = 0;
+    for (uint32_t k = 0; k < nk; k++) {
+        wv.acc = 0;
+        expand_window_runs(wv, runs, n_runs, group_run, g0 + k);
+        uint64_t t = wv.acc;
+        for (int d = 32; d >= 1; d >>= 1) t = sat_add(t, shfl64(t, (int)lane ^ d));
+        if (lane == 0) group_sums[g0 + k] = t;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the slice is staged into again
+    }
+    if (lane == 0 && wv.saw_patched) atomicOr(flags, 4u);
+}
+
+__global__ __launch_bounds__(VAL_WAVES * 64, 8) void rlev2_quad_sums_kernel(
+    const uint8_t *__restrict__ s, uint64_t len, const uint64_t *__restrict__ runs,
+    const RunEntry *__restrict__ group_run, uint32_t n_groups, uint32_t n_runs, uint64_t num_values,
+    int is_signed, uint64_t *__restrict__ group_sums, uint32_t *__restrict__ flags) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[VAL_WAVES][STAGE_WORDS];
+    __shared__ uint32_t marks[VAL_WAVES][WINDOW / 32];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t wg = blockIdx.x;  // XCD-contiguous remap, as in rlev2_values_kernel
+    {
+        const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, x = wg % 8;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + wg / 8;
+    }
+    const uint64_t g0_64 = ((uint64_t)wg * VAL_WAVES + wave) * SUMS_WINDOWS;
+    if (g0_64 >= n_groups) return;  // whole wavefront; no workgroup barrier below
+    const uint32_t g0 = (uint32_t)g0_64;
+    const uint32_t nk = n_groups - g0 < SUMS_WINDOWS ? n_groups - g0 : SUMS_WINDOWS;
+    uint32_t *lds = stage[wave];
+    // lane k: the entry of window g0 + k, and whether the window is of the simple kind
+    uint64_t desc = 0, out_off = 0;
+    if (lane < nk) {
+        desc = group_run[g0 + lane].desc;
+        out_off = group_run[g0 + lane].out_off;
+    }
+    const uint32_t w = desc_width(desc), rlen = desc_len(desc);
+    const uint64_t pay = desc_payload(desc);
+    const uint32_t n = (lane >= nk || out_off >= num_values) ? 0u
+                       : (num_values - out_off < rlen ? (uint32_t)(num_values - out_off) : rlen);
+    const uint32_t bytes = (w * n + 7) >> 3;  // of the values that are wanted
+    const uint32_t skew = (uint32_t)((uintptr_t)(s + pay) & 15);
+    const bool simple = lane >= nk || ((desc & DESC_SINGLE) && desc_kind(desc) == KIND_DIRECT && !is_signed && w <= 16 &&
+                                       pay <= len && bytes <= len - pay && bytes + skew <= 1024);
+    if (__ballot(!simple) == 0) {
+        uint4 v[SUMS_WINDOWS];
+#pragma unroll
+        for (uint32_t k = 0; k < SUMS_WINDOWS; k++) {
+            const uint64_t pay_k = readlane64(pay, (int)k);
+            const uint32_t bytes_k = readlane32(bytes, (int)k), skew_k = readlane32(skew, (int)k);
+            const uint32_t n16 = bytes_k ? (bytes_k + skew_k + 15) >> 4 : 0;  // at most 64
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (lane < n16) v[k] = ((const uint4 *)(s + pay_k - skew_k))[lane];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < SUMS_WINDOWS; k++) {
+            uint4 x = v[k];
+            x.x = __builtin_bswap32(x.x);
+            x.y = __builtin_bswap32(x.y);
+            x.z = __builtin_bswap32(x.z);
+            x.w = __builtin_bswap32(x.w);
+            ((uint4 *)(lds + k * SUMS_PITCH_WORDS))[lane] = x;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t k = 0; k < SUMS_WINDOWS; k++) {
+            const uint32_t w_k = readlane32(w, (int)k), n_k = readlane32(n, (int)k);
+            const uint32_t bit0 = readlane32(skew, (int)k) * 8;
+            const uint32_t *slot = lds + k * SUMS_PITCH_WORDS;
+            uint32_t part = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < WINDOW / 64; j++) {
+                const uint32_t idx = lane + 64 * j;
+                if (idx < n_k) part += lds_bits32(slot, bit0 + idx * w_k, w_k);
+            }
+            const uint32_t total = wave_scan_dpp(part);
+            if (lane == 63 && k < nk) group_sums[g0 + k] = total;
+        }
+        return;
+    }
+    // windows of other kinds: one by one (a call, so that the simple windows above do not share
+    // their registers with the general expansion)
+    general_window_sums(s, len, runs, group_run, n_runs, num_values, is_signed, group_sums, flags, lds, marks[wave], g0, nk);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3 behind a plan of the column (rlev2_regular_plan_kernel): every window is one run, and its entry
 // in group_run says everything about it.  The same expansion as rlev2_values_kernel makes of a
 // single-run window, in a kernel of its own: without the code for windows that several runs share
@@ -3298,6 +3438,18 @@ hipError_t launch_rlev2_values(hipStream_t st, const Rlev2Table &t, int64_t *out
 
 hipError_t launch_rlev2_group_sums(hipStream_t st, const Rlev2Table &t, uint64_t *group_sums,
                                    uint32_t *flags) {
+    // tables of long runs: four windows to a wavefront (see rlev2_quad_sums_kernel);
+    // ORCD_WAVE_SUMS=1 in the environment: a wavefront per window always (for comparisons)
+    static const bool wave_sums = [] {
+        const char *e = getenv("ORCD_WAVE_SUMS");
+        return e && *e && *e != '0';
+    }();
+    if (!wave_sums && t.n_groups && t.runs && !rlev2_values_short_variant(t)) {
+        const uint64_t waves = ((uint64_t)t.n_groups + SUMS_WINDOWS - 1) / SUMS_WINDOWS;
+        rlev2_quad_sums_kernel<<<(uint32_t)((waves + VAL_WAVES - 1) / VAL_WAVES), VAL_WAVES * 64, 0, st>>>(
+            t.stream, t.len, t.runs, t.group_run, t.n_groups, t.n_runs, t.num_values, t.is_signed, group_sums, flags);
+        return hipGetLastError();
+    }
     return launch_values_mode<MODE_SUMS>(st, t, nullptr, group_sums, flags);
 }
 

@@ -265,3 +265,50 @@ def test_length_sums_that_overflow(gpu, oracle):
     ls = enc.direct(many, 56, False)
     rc_gpu, _, _ = gpu.string_direct(ls, data, 512)
     assert rc_gpu == OUT_OF_SPEC
+
+
+@pytest.mark.parametrize("width", [1, 2, 3, 5, 6, 7, 8, 11, 13, 15, 16, 17, 24])
+def test_full_runs_of_every_width_four_windows_to_a_wavefront(gpu, oracle, width):
+    """LENGTH streams of full Direct runs (what writers make of string lengths): windows of one run
+    each, summed four to a wavefront when the fields are at most 16 bits wide -- every residue of
+    the run's start modulo 16 bytes comes by with the odd widths -- and one by one otherwise; the
+    number of values wanted ends inside a run, at a run's end and inside a group of four."""
+    rng = np.random.default_rng(300 + width)
+    n_runs = 41
+    lens = rng.integers(0, min(3, 2**width), size=512 * n_runs - 100).astype(np.uint64)   # the last run is short
+    ls = _length_stream(lens, width)
+    data = bytes(rng.integers(32, 127, size=int(lens.sum()), dtype=np.uint8))
+    want = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    for n in (len(lens), 512 * 40, 512 * 38 + 1, 512 * 37 - 1, 512 * 4, 700, 512, 5):
+        rc_gpu, off, out = gpu.string_direct(ls, data[:int(want[n])], n)
+        assert rc_gpu == 0, (width, n)
+        assert (off == want[:n + 1]).all(), (width, n)
+        assert out.tobytes() == data[:int(want[n])]
+    rc_cpu, off_ref, _ = oracle.string_direct(ls, data, len(lens))
+    assert rc_cpu == 0 and (off_ref == want).all()
+
+
+def test_a_window_of_another_kind_among_full_runs(gpu, oracle):
+    """Full Direct runs with a ShortRepeat or Delta run of 512 values here and there: a wavefront
+    whose four windows are not all of the simple kind takes them one by one, with the same sums."""
+    rng = np.random.default_rng(31)
+    chunks, lens = [], []
+    for k in range(64):
+        if k % 5 == 3:
+            chunks += [enc.short_repeat(2, 8, False)] * 64          # 512 values in 64 runs
+            lens.append(np.full(512, 2, dtype=np.int64))
+        elif k % 7 == 6:
+            chunks.append(enc.delta(1, 0, 510, 0, False))             # 512 times the value 1
+            lens.append(np.full(512, 1, dtype=np.int64))
+        else:
+            v = rng.integers(0, 8, size=512).astype(np.uint64)
+            chunks.append(enc.direct(v, 3, False))
+            lens.append(v.astype(np.int64))
+    ls, lens = b"".join(chunks), np.concatenate(lens)
+    data = bytes(rng.integers(32, 127, size=int(lens.sum()), dtype=np.uint8))
+    want = np.concatenate([[0], np.cumsum(lens)])
+    rc_cpu, off_ref, _ = oracle.string_direct(ls, data, len(lens))
+    assert rc_cpu == 0 and (off_ref == want).all()
+    for n in (len(lens), len(lens) - 300, 512 * 9 + 17):
+        rc_gpu, off, out = gpu.string_direct(ls, data[:int(want[n])], n)
+        assert rc_gpu == 0 and (off == want[:n + 1]).all(), n
