@@ -856,17 +856,19 @@ __global__ __launch_bounds__(256) void rlev2_emit_staged_kernel(
     const uint64_t *__restrict__ seg_ends, uint32_t n_seg, int is_signed, SegTable t,
     const uint64_t *__restrict__ staged, uint32_t staged_cap, uint64_t *__restrict__ runs,
     uint32_t *__restrict__ group_first, RunEntry *__restrict__ group_run, uint32_t n_group_slots,
-    int full_table, uint32_t group) {
+    int full_table, uint32_t group, uint32_t sets) {
     // `group` lanes per segment (a power of two from 8 to 64): a wavefront takes 64 / group
     // segments at a time, and two such sets one after the other -- what both need from memory
     // is asked for before either is worked on: a wavefront that emits 64 runs lives for one memory
     // round trip and little else, and 25 million runs are 400 000 of them.  (2.5 * 10^7 runs:
-    // 0.138 -> 0.128 ms with two sets, 0.115 ms with the scan of a full-wavefront group by DPP.)
+    // 0.138 -> 0.128 ms with two sets, 0.117 ms with the scan of a full-wavefront group by DPP.)
+    // (`sets` = 1: one set only, for tables of few segments, whose wavefronts are too few to
+    // keep the chip busy as it is)
     const uint32_t per_pass = 256 / group;  // segments a workgroup takes per pass
     const uint32_t lane = threadIdx.x & (group - 1);
-    const uint64_t seg_a = (uint64_t)blockIdx.x * 2 * per_pass + threadIdx.x / group, seg_b = seg_a + per_pass;
+    const uint64_t seg_a = (uint64_t)blockIdx.x * sets * per_pass + threadIdx.x / group, seg_b = seg_a + per_pass;
     if (seg_a >= n_seg) return;
-    const bool has_b = seg_b < n_seg;
+    const bool has_b = sets == 2 && seg_b < n_seg;
     // (a staged slot that was never written holds whatever it held; it is not looked at)
     const uint64_t word_a = staged[seg_a * staged_cap + lane];  // staged_cap >= 64 >= group
     const uint64_t word_b = has_b ? staged[seg_b * staged_cap + lane] : 0;
@@ -962,10 +964,20 @@ __global__ __launch_bounds__(256) void rlev2_emit_staged_kernel(
             carry_prev = __shfl(rlen, (int)group - 1, (int)group);
         }
     };
+    // a segment with more runs than the group has lanes: a group at a time, the words of the two
+    // chunks ahead already asked for (one load per chunk and nothing else to wait for: a file's
+    // segment of 2 000 runs is 32 dependent round trips otherwise)
+    // (base + lane < staged_cap for base < n_runs: both are multiples of group)
+    uint64_t ahead1 = 0, ahead2 = 0;
+    if (n_runs > group) {
+        ahead1 = mine[group + lane];
+        if (2 * group < n_runs) ahead2 = mine[2 * group + lane];
+    }
     chunk(0);
-    // a segment with more runs than the group has lanes: the rest, a group at a time
     for (uint32_t base = group; base < n_runs; base += group) {
-        staged_word = mine[base + lane];  // base + lane < staged_cap (both multiples of group)
+        staged_word = ahead1;
+        ahead1 = ahead2;
+        if (base + 2 * group < n_runs) ahead2 = mine[base + 2 * group + lane];
         chunk(base);
     }
     };
@@ -3347,11 +3359,13 @@ hipError_t launch_rlev2_emit_staged(hipStream_t st, const uint8_t *stream, uint6
                                     RunEntry *group_run, uint32_t n_group_slots, bool full_table,
                                     uint32_t max_seg_runs) {
     const uint32_t group = staged_group_lanes(max_seg_runs);
-    const uint64_t blocks = ((uint64_t)n_seg * group + 511) / 512;  // two passes of 256 / group segments each
+    // two sets of 256 / group segments per workgroup once there are wavefronts to spare
+    const uint32_t sets = (uint64_t)n_seg * group >= 64ull * 256 * 64 ? 2 : 1;
+    const uint64_t blocks = ((uint64_t)n_seg * group + 256 * sets - 1) / (256 * sets);
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     rlev2_emit_staged_kernel<<<(uint32_t)blocks, 256, 0, st>>>(stream, len, entries, seg_ends, n_seg, is_signed, t,
                                                      staged, staged_cap, runs, group_first, group_run,
-                                                     n_group_slots, full_table ? 1 : 0, group);
+                                                     n_group_slots, full_table ? 1 : 0, group, sets);
     return hipGetLastError();
 }
 
