@@ -1,5 +1,5 @@
-"""Differential fuzz of the wavefront-per-segment header pass against the CPU oracle: random RLE v2
-streams of every run kind, with and without entry points, cut, corrupted and with garbage tails
+"""Differential fuzz of the header passes against the CPU oracle: random RLE v2 streams of every run
+kind and random byte-RLE / boolean streams, with and without entry points, cut, corrupted and with garbage tails
 (python3 tests/fuzz_coop.py [rounds]; not collected by pytest: a longer soak than the suite affords)."""
 import os, sys
 import numpy as np
@@ -49,5 +49,55 @@ for it in range(rounds):
         print("MISMATCH round", it, "mode", mode, "kinds", kinds, "n_runs", n_runs, "max_len", max_len, "rc oracle", rc, "gpu", got, flush=True)
     if it % 50 == 49:
         print("round", it + 1, "mismatches", bad, flush=True)
-print("done:", rounds, "rounds,", bad, "mismatches")
+
+def byte_rle_starts(stream):
+    starts, pos = [], 0
+    while pos < len(stream):
+        starts.append(pos)
+        c = stream[pos]
+        pos += 2 if c < 128 else 1 + (256 - c)
+    return starts
+
+
+# byte-RLE / boolean streams the same way
+for it in range(rounds):
+    n_bytes = int(rng.choice([5, 200, 5000, 150000]))
+    style = int(rng.integers(0, 3))
+    if style == 0:
+        data = bytes(rng.integers(0, 256, size=n_bytes, dtype=np.uint8))
+    elif style == 1:
+        data = np.packbits(rng.random(n_bytes * 8) < rng.choice([0.5, 0.9, 0.99])).tobytes()
+    else:
+        data = b"".join(bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 200)) for _ in range(max(1, n_bytes // 60)))
+    stream = enc.byte_rle(data, max_literal=int(rng.choice([3, 17, 128])))
+    n = len(data) * 8
+    mode = int(rng.integers(0, 5))
+    s = stream
+    if mode == 1 and len(s) > 2:
+        s = s[:int(rng.integers(1, len(s)))]
+    elif mode == 2:
+        b = bytearray(s); k = int(rng.integers(0, len(b))); b[k] ^= 1 << int(rng.integers(0, 8)); s = bytes(b)
+    elif mode == 3:
+        n = n + int(rng.integers(1, 4000))
+    elif mode == 4:
+        n = max(1, n - int(rng.integers(0, n)))
+    entries = None
+    starts = byte_rle_starts(stream)
+    if mode in (0, 4) and len(starts) > 8 and rng.integers(0, 2):
+        step = int(rng.integers(1, max(2, len(starts) // 4)))
+        entries = np.array(starts[::step], dtype=np.uint64)
+    rc, ref, ones_ref = oracle.boolean(s, n)
+    try:
+        out, ones = ctx.boolean(s, n, entries)
+        ok = rc == 0 and np.array_equal(out.astype(bool), ref) and ones == ones_ref
+        got = 0
+    except OrcError as e:
+        got = e.code
+        ok = got == rc
+    if not ok:
+        bad += 1
+        print("MISMATCH boolean round", it, "mode", mode, "style", style, "bytes", n_bytes, "rc oracle", rc, "gpu", got, flush=True)
+    if it % 100 == 99:
+        print("boolean round", it + 1, "mismatches", bad, flush=True)
+print("done:", rounds, "rounds of each,", bad, "mismatches")
 sys.exit(1 if bad else 0)
