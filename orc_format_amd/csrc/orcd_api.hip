@@ -1417,24 +1417,64 @@ int plan_segments(const orcd_rlev2_slice *slices, size_t n_slices, size_t buffer
 }
 
 // Decoded as one stream, the items of a slice land where they belong only if every slice before
-// it holds exactly what it was said to hold: compares the scan's offsets at the slice starts
-// with the prefix sums of the counts.
-int verify_slice_offsets(orcd_ctx *c, const SegTable &seg, const SegmentPlan &plan, const uint32_t *d_first,
-                         size_t *bad_slice) {
-    void *d_val_off;
-    ORCD_TRY(ensure(c, SLOT_TMP, plan.first_seg.size() * sizeof(uint64_t), &d_val_off));
-    std::vector<uint64_t> got_off(plan.first_seg.size());
-    HIP_TRY(c, launch_seg_value_offsets(c->stream, seg, d_first, (uint32_t)plan.first_seg.size(),
-                                        (uint64_t *)d_val_off));
-    HIP_TRY(c, hipMemcpyAsync(got_off.data(), d_val_off, got_off.size() * sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (size_t k = 0; k < got_off.size(); k++) {
-        if (got_off[k] != plan.want_off[k]) {  // slice k - 1 is the first that is off
-            if (bad_slice) *bad_slice = plan.slice_of[k ? k - 1 : 0];
-            return ORCD_OUT_OF_SPEC;
-        }
+// it holds exactly what it was said to hold: the scan's offsets at the slice starts are compared
+// with the prefix sums of the counts -- on the device, the verdict left in pinned host memory
+// behind a stamp, so that the expansion can be queued behind the check and the host learns the
+// verdict while it runs (a copy back and a wait for the stream left the device idle for 40
+// microseconds per batch).
+int verify_slices_launch(orcd_ctx *c, const SegTable &seg, const uint32_t *d_first, const uint64_t *d_want,
+                         size_t n, uint32_t *stamp) {
+    *stamp = next_stamp(c);
+    HIP_TRY(c, launch_seg_offsets_verify(c->stream, seg, d_first, d_want, (uint32_t)n, c->h_scalars + 6, *stamp));
+    return ORCD_OK;
+}
+
+int verify_slices_wait(orcd_ctx *c, uint32_t stamp, const SegmentPlan &plan, size_t *bad_slice) {
+    volatile uint64_t *h = c->h_scalars + 6;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (uint32_t spins = 0; !(seen = h[1] == stamp); spins++) {
+        if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
     }
+    if (!seen) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (h[1] != stamp) return ORCD_HIP_ERROR;  // the kernel did not reach its end
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const uint64_t k = h[0];
+    if (k != 0xFFFFFFFFull) {  // slice k - 1 is the first that is off
+        if (bad_slice) *bad_slice = plan.slice_of[k && k <= plan.slice_of.size() ? k - 1 : 0];
+        return ORCD_OUT_OF_SPEC;
+    }
+    return ORCD_OK;
+}
+
+// The plan's arrays in one piece, so that they reach the device in one copy: starts | ends |
+// want_off | first_seg (32-bit).  Pointers into the device copy come back.
+struct PlanOnDevice {
+    const uint64_t *starts, *ends, *want_off;
+    const uint32_t *first_seg;
+    const uint64_t *extra;  // the caller's own words, behind the plan's
+};
+
+int upload_plan(orcd_ctx *c, const SegmentPlan &plan, std::vector<uint64_t> &pack, PlanOnDevice *d,
+                const std::vector<uint64_t> &extra = {}) {
+    const size_t n_seg = plan.starts.size(), n_sl = plan.first_seg.size();
+    const size_t at_extra = 2 * n_seg + n_sl + (n_sl + 1) / 2;
+    pack.resize(at_extra + extra.size());
+    memcpy(pack.data(), plan.starts.data(), n_seg * sizeof(uint64_t));
+    memcpy(pack.data() + n_seg, plan.ends.data(), n_seg * sizeof(uint64_t));
+    memcpy(pack.data() + 2 * n_seg, plan.want_off.data(), n_sl * sizeof(uint64_t));
+    memcpy(pack.data() + 2 * n_seg + n_sl, plan.first_seg.data(), n_sl * sizeof(uint32_t));
+    if (!extra.empty()) memcpy(pack.data() + at_extra, extra.data(), extra.size() * sizeof(uint64_t));
+    const void *p;
+    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, pack.data(), pack.size() * sizeof(uint64_t), false, &p));
+    const uint64_t *base = (const uint64_t *)p;
+    d->starts = base;
+    d->ends = base + n_seg;
+    d->want_off = base + 2 * n_seg;
+    d->first_seg = (const uint32_t *)(base + 2 * n_seg + n_sl);
+    d->extra = base + at_extra;
     return ORCD_OK;
 }
 
@@ -1456,11 +1496,11 @@ int orcd_rlev2_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_le
     reset_events(c);
     const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
     mark(c, 0);
-    const void *d_buffer, *d_starts, *d_ends, *d_first;
+    const void *d_buffer;
     ORCD_TRY(stage_in(c, SLOT_IN_A, buffer, buffer_len, in_dev, &d_buffer));
-    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, plan.starts.data(), plan.starts.size() * sizeof(uint64_t), false, &d_starts));
-    ORCD_TRY(stage_in(c, SLOT_IN_C, plan.ends.data(), plan.ends.size() * sizeof(uint64_t), false, &d_ends));
-    ORCD_TRY(stage_in(c, SLOT_IN_D, plan.first_seg.data(), plan.first_seg.size() * sizeof(uint32_t), false, &d_first));
+    std::vector<uint64_t> pack;
+    PlanOnDevice dp;
+    ORCD_TRY(upload_plan(c, plan, pack, &dp));
     int64_t *d_out = out;
     if (!out_dev) {
         void *p;
@@ -1469,17 +1509,20 @@ int orcd_rlev2_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_le
     }
     Rlev2Table t;
     SegTable seg = {};
-    const int rc = rlev2_table(c, (const uint8_t *)d_buffer, buffer_len, total_values, (const uint64_t *)d_starts,
-                               plan.starts.size(), (flags & ORCD_SIGNED) ? 1 : 0, &t, false,
-                               (const uint64_t *)d_ends, &seg);
+    const int rc = rlev2_table(c, (const uint8_t *)d_buffer, buffer_len, total_values, dp.starts,
+                               plan.starts.size(), (flags & ORCD_SIGNED) ? 1 : 0, &t, false, dp.ends, &seg);
     if (!seg.seg_local) return rc;  // failed before the scan: there is nothing to look at
-    ORCD_TRY(verify_slice_offsets(c, seg, plan, (const uint32_t *)d_first, bad_slice));
+    uint32_t verdict_stamp;
+    ORCD_TRY(verify_slices_launch(c, seg, dp.first_seg, dp.want_off, plan.first_seg.size(), &verdict_stamp));
     if (rc != ORCD_OK) {  // a run that does not parse, or too few values: in or after the last good start
+        ORCD_TRY(verify_slices_wait(c, verdict_stamp, plan, bad_slice));
         if (bad_slice) *bad_slice = plan.slice_of.back();
         return rc;
     }
+    // (the tables are sound whatever the verdict: the expansion writes total_values values at most)
     HIP_TRY(c, launch_rlev2_values(c->stream, t, d_out));
     mark(c, 3);
+    ORCD_TRY(verify_slices_wait(c, verdict_stamp, plan, bad_slice));
     if (!out_dev) ORCD_TRY(copy_out(c, out, d_out, total_values * sizeof(int64_t)));
     return ORCD_OK;
 } ORCD_CATCH
@@ -1500,11 +1543,21 @@ int orcd_boolean_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_
     reset_events(c);
     const bool in_dev = flags & ORCD_IN_DEVICE, out_dev = flags & ORCD_OUT_DEVICE;
     mark(c, 0);
-    const void *d_buffer, *d_starts, *d_ends, *d_first;
+    const void *d_buffer;
     ORCD_TRY(stage_in(c, SLOT_IN_A, buffer, buffer_len, in_dev, &d_buffer));
-    ORCD_TRY(stage_in(c, SLOT_IN_ENTRIES, plan.starts.data(), plan.starts.size() * sizeof(uint64_t), false, &d_starts));
-    ORCD_TRY(stage_in(c, SLOT_IN_C, plan.ends.data(), plan.ends.size() * sizeof(uint64_t), false, &d_ends));
-    ORCD_TRY(stage_in(c, SLOT_IN_D, plan.first_seg.data(), plan.first_seg.size() * sizeof(uint32_t), false, &d_first));
+    // (for the counts of set bits: per slice, where its values start in the output and how many
+    // there are -- sent along with the plan)
+    std::vector<uint64_t> where;
+    if (set_bits) {
+        where.resize(2 * plan.slice_of.size());
+        for (size_t k = 0; k < plan.slice_of.size(); k++) {
+            where[k] = plan.want_off[k] * 8;
+            where[plan.slice_of.size() + k] = slices[plan.slice_of[k]].num_values;
+        }
+    }
+    std::vector<uint64_t> pack;
+    PlanOnDevice dp;
+    ORCD_TRY(upload_plan(c, plan, pack, &dp, where));
     uint8_t *d_out = out_bytes;
     if (!out_dev) {
         void *p;
@@ -1513,11 +1566,13 @@ int orcd_boolean_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_
     }
     ByteRleTable t;
     SegTable seg = {};
-    const int rc = byte_rle_table(c, (const uint8_t *)d_buffer, buffer_len, total_bytes, (const uint64_t *)d_starts,
-                                  plan.starts.size(), &t, (const uint64_t *)d_ends, &seg);
+    const int rc = byte_rle_table(c, (const uint8_t *)d_buffer, buffer_len, total_bytes, dp.starts,
+                                  plan.starts.size(), &t, dp.ends, &seg);
     if (!seg.seg_local) return rc;
-    ORCD_TRY(verify_slice_offsets(c, seg, plan, (const uint32_t *)d_first, bad_slice));
+    uint32_t verdict_stamp;
+    ORCD_TRY(verify_slices_launch(c, seg, dp.first_seg, dp.want_off, plan.first_seg.size(), &verdict_stamp));
     if (rc != ORCD_OK) {
+        ORCD_TRY(verify_slices_wait(c, verdict_stamp, plan, bad_slice));
         if (bad_slice) *bad_slice = plan.slice_of.back();
         return rc;
     }
@@ -1526,21 +1581,14 @@ int orcd_boolean_decode_batch(orcd_ctx *c, const uint8_t *buffer, size_t buffer_
     HIP_TRY(c, launch_bool_expand(c->stream, (const uint8_t *)d_buffer, buffer_len, t.runs, t.win_first,
                                   t.n_win_slots, t.n_runs, total_bytes * 8, d_out, nullptr, nullptr));
     mark(c, 3);
+    ORCD_TRY(verify_slices_wait(c, verdict_stamp, plan, bad_slice));
     if (set_bits) {
-        // per slice: where its values start in the output and how many there are
-        std::vector<uint64_t> where(2 * plan.slice_of.size());
-        for (size_t k = 0; k < plan.slice_of.size(); k++) {
-            where[k] = plan.want_off[k] * 8;
-            where[plan.slice_of.size() + k] = slices[plan.slice_of[k]].num_values;
-        }
-        const void *d_where;
+        const uint64_t *d_where = dp.extra;
         void *d_counts;
-        ORCD_TRY(stage_in(c, SLOT_IN_B, where.data(), where.size() * sizeof(uint64_t), false, &d_where));
         ORCD_TRY(ensure(c, SLOT_TMP, plan.slice_of.size() * sizeof(uint64_t), &d_counts));
         uint64_t largest = 0;
         for (size_t k = 0; k < plan.slice_of.size(); k++) largest = std::max<uint64_t>(largest, slices[plan.slice_of[k]].num_values);
-        HIP_TRY(c, launch_count_nonzero_slices(c->stream, d_out, (const uint64_t *)d_where,
-                                               (const uint64_t *)d_where + plan.slice_of.size(),
+        HIP_TRY(c, launch_count_nonzero_slices(c->stream, d_out, d_where, d_where + plan.slice_of.size(),
                                                (uint32_t)plan.slice_of.size(), (uint64_t *)d_counts, largest));
         std::vector<uint64_t> counts(plan.slice_of.size());
         HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, counts.size() * sizeof(uint64_t),

@@ -160,6 +160,10 @@ hipError_t launch_rlev2_probe(hipStream_t st, const uint8_t *stream, uint64_t le
                               int is_signed, uint64_t *out);
 hipError_t launch_rlev2_verify_stride(hipStream_t st, const uint8_t *stream, uint64_t len, uint64_t p,
                                       uint64_t stride, uint64_t n, int is_signed, uint64_t *first_fail);
+// first k < n whose segment first_seg[k] does not have want_off[k] values before it -> host_word[0]
+// (0xFFFFFFFF: none), then `stamp` -> host_word[1]; host_word: host memory the device can write
+hipError_t launch_seg_offsets_verify(hipStream_t st, const SegTable &t, const uint32_t *first_seg,
+                                     const uint64_t *want_off, uint32_t n, uint64_t *host_word, uint32_t stamp);
 hipError_t launch_seg_value_offsets(hipStream_t st, const SegTable &t, const uint32_t *first_seg,
                                     uint32_t n, uint64_t *out);
 // What the header scan leaves for the value kernels of one stream.

@@ -3421,6 +3421,32 @@ __global__ void seg_value_offsets_kernel(SegTable t, const uint32_t *__restrict_
     if (i < n) out[i] = seg_global_offset(t, first_seg[i]).val_off;
 }
 
+// Whether the values before segment first_seg[k] are want_off[k] of them, for every k < n: the
+// first k for which they are not (0xFFFFFFFF: none) goes to host_word[0] -- host memory the device
+// can write -- and `stamp` to host_word[1] after it, for a host that watches for the stamp.
+__global__ __launch_bounds__(256) void seg_offsets_verify_kernel(SegTable t, const uint32_t *__restrict__ first_seg,
+                                                                 const uint64_t *__restrict__ want_off, uint32_t n,
+                                                                 uint64_t *host_word, uint32_t stamp) {
+    __shared__ uint32_t first_bad;
+    if (threadIdx.x == 0) first_bad = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n; k += 256)
+        if (seg_global_offset(t, first_seg[k]).val_off != want_off[k]) atomicMin(&first_bad, k);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        volatile uint64_t *h = host_word;
+        h[0] = first_bad;
+        __threadfence_system();
+        h[1] = stamp;
+    }
+}
+
+hipError_t launch_seg_offsets_verify(hipStream_t st, const SegTable &t, const uint32_t *first_seg,
+                                     const uint64_t *want_off, uint32_t n, uint64_t *host_word, uint32_t stamp) {
+    seg_offsets_verify_kernel<<<1, 256, 0, st>>>(t, first_seg, want_off, n, host_word, stamp);
+    return hipGetLastError();
+}
+
 hipError_t launch_seg_value_offsets(hipStream_t st, const SegTable &t, const uint32_t *first_seg,
                                     uint32_t n, uint64_t *out) {
     if (n == 0) return hipSuccess;
