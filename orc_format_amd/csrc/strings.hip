@@ -799,7 +799,10 @@ hipError_t launch_dictionary_gather(hipStream_t st, const int64_t *dict_offsets,
                                     int64_t *offsets_out, uint8_t *bytes_out, uint32_t max_len, uint64_t capacity) {
     if (n == 0) return hipSuccess;
     const uint64_t chunks = (n + 63) / 64;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((chunks + DG_WAVES - 1) / DG_WAVES, 256 * 4);  // workgroups take chunks in turn
+    // workgroups take chunks in turn; 32 of them per compute unit rather than as many as fit at
+    // once (4): 1.10 -> 1.05 ms per 10^8 values of 4..28 bytes, 9.8 -> 8.5 ms with values of up to
+    // 200 bytes -- the tail of a grid that only just fills the chip is long when chunks differ
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((chunks + DG_WAVES - 1) / DG_WAVES, 256 * 32);
     const uint64_t lds = ((dict_size + 1) * 4 + 15) / 16 * 16 + dict_total + 16;
     const bool in_lds = lds <= DG_DICT_LDS && dict_total < 0xFFFFFFFFull;
     const bool is_short = max_len <= DG_SHORT_LEN;  // max_len: of the dictionary's entries (dictionary_max_len_kernel)
