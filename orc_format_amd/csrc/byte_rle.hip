@@ -562,7 +562,15 @@ __global__ __launch_bounds__(256) void byte_rle_tile_kernel(
             const uint4 *src16 = (const uint4 *)(sb - skew);  // aligned chunks that each hold a byte of the stretch
             const uint32_t n16 = (uint32_t)((span + skew + 15) >> 4);
             uint4 *dst16 = (uint4 *)(L.bytes + BX_PAD / 4);
-            for (uint32_t c = lane; c < n16; c += 64) dst16[c] = src16[c];
+            // loads that write LDS themselves, 1 KiB per instruction (lane i's 16 bytes land at the
+            // instruction's LDS address + 16 i): all of the stretch is asked for at once -- a loop
+            // that stores each KiB before it asks for the next pays a memory round trip per KiB,
+            // and a tile's stretch is four of them
+            for (uint32_t c0 = 0; c0 < n16; c0 += 64)
+                if (c0 + lane < n16)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src16 + c0 + lane),
+                                                     (__attribute__((address_space(3))) void *)(dst16 + c0), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             L.rel[lane] = my_rel;
             L.srel[lane] = (uint32_t)((my_src & PAYLOAD_MASK) - src0) | ((my_src & BR_IS_RUN) ? 0x80000000u : 0u);
             if (lane < 2) {
